@@ -1,0 +1,204 @@
+/*
+ * mhlik.h -- C-ABI of the MI355X Metropolis-Hastings likelihood library
+ * (libmhlik.so).  Plain C types only: no HIP, torch or C++ types cross this
+ * boundary.
+ *
+ * What it replaces in the reference (cstyl/mcmc), call for call:
+ *
+ *   cudaMalloc x4 + cudaMemcpy of X   src/mcmc_gpu/mcmc_gpu.cu:53-58, 409-414
+ *                                     -> mhlik_create + mhlik_upload_f64/_f32
+ *                                        (once per dataset, shared by tuner
+ *                                        and sampler)
+ *   gpu_likelihood_d + reduction_d    src/mcmc_gpu/mcmc_gpu.cu:214-257,177-212
+ *     (cublasDgemv, reduceRegr2,      src/reduction/reduction_kernel.cu:140-167,
+ *      reduce2 passes, D2H + CPU sum)   253-280, 387-458
+ *                                     -> mhlik_loglik_f64
+ *   gpu_likelihood_f + reduction_f    src/mcmc_gpu_sp/mcmc_gpu_sp.cu:216-264,179-214
+ *                                     -> mhlik_loglik_f32
+ *   mp_likelihood + mcmc_mp_kernel    src/mcmc_mp/mcmc_mp.cu:475-552, 28-200
+ *     + reduction_mp_d/_f               554-627
+ *                                     -> mhlik_mp_loglik
+ *   likelihood_bound/call_boundKernel src/mcmc_mp/mcmc_mp.cu:746-821, 202-280
+ *                                     -> mhlik_mp_bound
+ *   cudaFree x4                       src/mcmc_gpu/mcmc_gpu.cu:78-81
+ *                                     -> mhlik_destroy
+ *
+ * The log-likelihood is  L(theta) = - sum_i log(1 + exp(sum_j X[i,j]*theta[j]))
+ * with X[i,j] = -y_i * x_ij (label folded in, src/util/data_util.c:33).
+ *
+ * Threading: a context is not re-entrant; one host thread drives it.  Every
+ * evaluation call blocks until its result is on the host, like the
+ * reference's (the value feeds the host accept test, mcmc_gpu.cu:107-114).
+ * All sizes that can exceed 2^31 are int64_t (the reference overflows int at
+ * N=1e8, d=64: mcmc_gpu.cu:48).
+ */
+#ifndef MHLIK_H
+#define MHLIK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mhlik_ctx mhlik_ctx;
+
+/* status codes (0 = ok); text via mhlik_last_error */
+enum {
+  MHLIK_OK = 0,
+  MHLIK_EINVAL = 1, /* bad argument */
+  MHLIK_ENOMEM = 2, /* host or device allocation failed */
+  MHLIK_EHIP = 3,   /* a HIP runtime call failed */
+  MHLIK_ESTATE = 4, /* call not valid in this state (e.g. no data uploaded) */
+  MHLIK_ECOMM = 5   /* RCCL not available / collective failed */
+};
+
+/* which copies of the design matrix the context keeps in HBM (bit mask) */
+enum { MHLIK_F64 = 1, MHLIK_F32 = 2 };
+
+/* HBM layout of the design matrix */
+enum {
+  MHLIK_LAYOUT_DEFAULT = 0,
+  MHLIK_LAYOUT_TILED = 1,   /* [tile][column][row-in-tile], tile contiguous */
+  MHLIK_LAYOUT_COLMAJOR = 2 /* the reference's column-major, padded lda */
+};
+
+#define MHLIK_MAX_SEGMENTS 64
+#define MHLIK_MAX_BATCH 64
+#define MHLIK_COMM_ID_BYTES 128
+
+typedef struct mhlik_config {
+  int64_t n_rows;    /* N: rows of the whole (global) design matrix */
+  int32_t n_cols;    /* d: columns, bias included */
+  int32_t precision; /* MHLIK_F64 | MHLIK_F32 */
+  int32_t device;    /* HIP device ordinal; -1 = current device */
+  int32_t rank;      /* this context's shard, 0 <= rank < world */
+  int32_t world;     /* number of shards (processes, one GPU each); 1 = no sharding */
+  int32_t segments;  /* fixed row segments the sum is grouped by; 0 = 8.
+                        Must be a multiple of world.  The result is bitwise
+                        identical for every world that divides it. */
+  int32_t layout;    /* MHLIK_LAYOUT_* */
+  int32_t variant;   /* kernel variant; 0 = default (tuning knob) */
+  int32_t timing;    /* !=0: bracket the likelihood kernel with events */
+  int32_t reserved[6];
+} mhlik_config;
+
+/* Create a context on config->device.  Allocates nothing large until data is
+ * uploaded or filled.  On failure *out is NULL and mhlik_last_error(NULL)
+ * holds the reason. */
+int mhlik_create(const mhlik_config *config, mhlik_ctx **out);
+void mhlik_destroy(mhlik_ctx *ctx);
+
+/* Last error text of this context (ctx == NULL: of the last failed create). */
+const char *mhlik_last_error(const mhlik_ctx *ctx);
+
+/* Global row range [begin, begin+count) this shard holds. */
+int mhlik_local_rows(const mhlik_ctx *ctx, int64_t *begin, int64_t *count);
+
+/* Upload the shard from a host column-major matrix: global row g, column j
+ * is X[j*ld + (g - row0)].  Pass the whole matrix with row0 = 0, or only this
+ * shard's rows with row0 = its first global row.  Replaces the cudaMemcpy of
+ * data.data / data.dataf (mcmc_gpu.cu:58, mcmc_gpu_sp.cu:58, mcmc_mp.cu:320-321). */
+int mhlik_upload_f64(mhlik_ctx *ctx, const double *X, int64_t ld, int64_t row0);
+int mhlik_upload_f32(mhlik_ctx *ctx, const float *X, int64_t ld, int64_t row0);
+
+/* Fill the shard on the device with the seeded synthetic logistic-regression
+ * data set (distribution of scr/data_scr/synthetic_generation.py:33-65: bias
+ * column 1, other features U(0,1), integer beta in [-15,15) with beta_0 = 1,
+ * y = sign(x.beta), stored as -y*x).  Counter-based: any shard of any N is
+ * produced identically on any number of GPUs.  Fills every precision the
+ * context holds (the float copy is the rounded double, data_util.c:72). */
+int mhlik_fill_synthetic(mhlik_ctx *ctx, uint64_t seed);
+
+/* The same generator on the host: rows [row0, row0+rows) of the N x d data
+ * set, column-major with leading dimension ld.  For building the CPU copy
+ * that the oracle / CPU baseline reads. */
+int mhlik_synthetic_host_f64(uint64_t seed, int64_t n_rows, int32_t n_cols, int64_t row0, int64_t rows,
+                             double *X, int64_t ld);
+int mhlik_synthetic_beta(uint64_t seed, int32_t n_cols, int32_t *beta);
+
+/* Copy the shard back to the host as column-major (debug / tests). */
+int mhlik_download_f64(mhlik_ctx *ctx, double *X, int64_t ld);
+int mhlik_download_f32(mhlik_ctx *ctx, float *X, int64_t ld);
+
+/* L(theta) over ALL rows (all shards: with world > 1 every rank must call and
+ * every rank gets the same bits).  theta is a host array of n_cols values. */
+int mhlik_loglik_f64(mhlik_ctx *ctx, const double *theta, double *out);
+int mhlik_loglik_f32(mhlik_ctx *ctx, const float *theta, float *out);
+
+/* K proposals in one pass over X (X.Theta on the matrix cores).  Theta is
+ * host row-major [K][n_cols] (chain k contiguous); out[k] = L(Theta[k]).
+ * 1 <= K <= MHLIK_MAX_BATCH.  No counterpart in the reference (one chain,
+ * one theta per call: mcmc_gpu.cu:101-107); BASELINE.json config 5. */
+int mhlik_loglik_batched_f64(mhlik_ctx *ctx, const double *Theta, int32_t K, double *out);
+int mhlik_loglik_batched_f32(mhlik_ctx *ctx, const float *Theta, int32_t K, double *out);
+
+/* Per-row dot products x_i.theta of this shard's rows, to a host array of
+ * local-row-count doubles: the reference's data.mvout / d.cuLhood
+ * (mcmc_cpu.c:436, mcmc_gpu.cu:233).  Test / debug entry point. */
+int mhlik_rowdots_f64(mhlik_ctx *ctx, const double *theta, double *out);
+
+/* ---- mixed precision (src/mcmc_mp/mcmc_mp.cu) ------------------------- */
+
+typedef struct mhlik_mp_state {
+  int32_t block_rows;    /* mp_str.dataBlockSz */
+  int32_t blocks;        /* mp_str.dataBlocks (global) */
+  int32_t resamp_factor; /* mp_str.ResampFactor */
+  int32_t resamp_choose; /* gsl_rng_uniform_int(r, ResampFactor), mcmc_mp.cu:504 */
+  uint64_t u_seed;       /* seed of the per-block uniforms (reference: cuRAND, 1234) */
+  uint64_t u_call;       /* call counter: selects the uniforms of this call */
+  double bound_eps;      /* lhoodBound / `e` */
+} mhlik_mp_state;
+
+/* (Re)initialise the bright/dark indicators: every block bright (mcmc_mp.cu:323). */
+int mhlik_mp_reset(mhlik_ctx *ctx, int32_t block_rows, int32_t blocks);
+
+/* One mixed-precision likelihood evaluation (mp_likelihood, mcmc_mp.cu:475-552):
+ * float dots for all rows, double dots for bright / resampled blocks, z
+ * resampling.  Returns red_d + red_f and the new bright / dark block counts. */
+int mhlik_mp_loglik(mhlik_ctx *ctx, const mhlik_mp_state *st, const double *theta, double *out,
+                    int32_t *bright_blocks, int32_t *dark_blocks);
+
+/* likelihood_bound (mcmc_mp.cu:746-821): sum of double sigmoids and the
+ * extreme of epsilon_i = sigma_D - sigma_S over all rows. */
+int mhlik_mp_bound(mhlik_ctx *ctx, const double *theta, double *sum_lb, double *epsilon);
+
+/* ---- multi-GPU (no counterpart: the reference is single-GPU, mcmc_gpu.cu:28) */
+
+/* Rank 0 makes an id, the host layer ships the bytes to every rank (e.g. a
+ * torch.distributed broadcast), every rank calls mhlik_comm_init.  After it,
+ * each evaluation all-reduces the per-segment partial sums over RCCL/xGMI. */
+int mhlik_comm_make_id(uint8_t id[MHLIK_COMM_ID_BYTES]);
+int mhlik_comm_init(mhlik_ctx *ctx, const uint8_t id[MHLIK_COMM_ID_BYTES]);
+
+/* Without RCCL (tests, other transports): get this rank's per-segment sums
+ * of the LAST evaluation / set the combined ones.  seg_sums has
+ * config.segments entries, zero where this rank holds no rows. */
+int mhlik_last_segment_sums(const mhlik_ctx *ctx, double *seg_sums);
+
+/* ---- instrumentation --------------------------------------------------- */
+
+/* Device time of the last likelihood kernel in ms (config.timing != 0) and
+ * the algorithmic bytes it read (local rows * n_cols * sizeof(T)). */
+int mhlik_last_kernel_ms(const mhlik_ctx *ctx, float *ms, int64_t *bytes);
+
+/* Geometry actually used (for DESIGN.md / bench reporting). */
+typedef struct mhlik_info {
+  int64_t local_rows;
+  int64_t tiles_f64, tiles_f32;
+  int32_t tile_rows_f64, tile_rows_f32;
+  int32_t layout, variant;
+  int32_t compute_units;
+  int32_t reserved;
+  int64_t hbm_bytes; /* device bytes held by the context */
+} mhlik_info;
+int mhlik_get_info(const mhlik_ctx *ctx, mhlik_info *info);
+
+/* Library version string. */
+const char *mhlik_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MHLIK_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libmhlik.so (include/mhlik.h).  Fails loudly when the
+library is missing: there is no Python or CPU substitute for the HIP path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+MAX_SEGMENTS = 64
+MAX_BATCH = 64
+COMM_ID_BYTES = 128
+
+
+class MhlikError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("mhlik error %d: %s" % (code, text))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64),
+        ("n_cols", C.c_int32),
+        ("precision", C.c_int32),
+        ("device", C.c_int32),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("segments", C.c_int32),
+        ("layout", C.c_int32),
+        ("variant", C.c_int32),
+        ("timing", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("local_rows", C.c_int64),
+        ("tiles_f64", C.c_int64),
+        ("tiles_f32", C.c_int64),
+        ("tile_rows_f64", C.c_int32),
+        ("tile_rows_f32", C.c_int32),
+        ("layout", C.c_int32),
+        ("variant", C.c_int32),
+        ("compute_units", C.c_int32),
+        ("reserved", C.c_int32),
+        ("hbm_bytes", C.c_int64),
+    ]
+
+
+class MpState(C.Structure):
+    _fields_ = [
+        ("block_rows", C.c_int32),
+        ("blocks", C.c_int32),
+        ("resamp_factor", C.c_int32),
+        ("resamp_choose", C.c_int32),
+        ("u_seed", C.c_uint64),
+        ("u_call", C.c_uint64),
+        ("bound_eps", C.c_double),
+    ]
+
+
+def lib_path(name="libmhlik.so"):
+    return os.path.join(_HERE, "lib", name)
+
+
+_lib = None
+
+# every symbol include/mhlik.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGS = [
+    ("mhlik_create", C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    ("mhlik_destroy", None, [_P]),
+    ("mhlik_last_error", C.c_char_p, [_P]),
+    ("mhlik_local_rows", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mhlik_upload_f64", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("mhlik_upload_f32", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("mhlik_fill_synthetic", C.c_int, [_P, C.c_uint64]),
+    ("mhlik_synthetic_host_f64", C.c_int, [C.c_uint64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, _P, C.c_int64]),
+    ("mhlik_synthetic_beta", C.c_int, [C.c_uint64, C.c_int32, _P]),
+    ("mhlik_download_f64", C.c_int, [_P, _P, C.c_int64]),
+    ("mhlik_download_f32", C.c_int, [_P, _P, C.c_int64]),
+    ("mhlik_loglik_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    ("mhlik_loglik_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    ("mhlik_loglik_batched_f64", C.c_int, [_P, _P, C.c_int32, _P]),
+    ("mhlik_loglik_batched_f32", C.c_int, [_P, _P, C.c_int32, _P]),
+    ("mhlik_rowdots_f64", C.c_int, [_P, _P, _P]),
+    ("mhlik_mp_reset", C.c_int, [_P, C.c_int32, C.c_int32]),
+    ("mhlik_mp_loglik", C.c_int, [_P, C.POINTER(MpState), _P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("mhlik_mp_bound", C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("mhlik_comm_make_id", C.c_int, [_P]),
+    ("mhlik_comm_init", C.c_int, [_P, _P]),
+    ("mhlik_last_segment_sums", C.c_int, [_P, _P]),
+    ("mhlik_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    ("mhlik_get_info", C.c_int, [_P, C.POINTER(Info)]),
+    ("mhlik_version", C.c_char_p, []),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
+
+
+def load_mhlik():
+    """Load libmhlik.so and declare its prototypes.  Raises if it is missing:
+    build it with `python -c "import __graft_entry__ as g; g.build()"` or
+    `make -C mcmc_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "mcmc_amd: %s not found -- the MI355X likelihood path has no CPU fallback; "
+            "build it with `make -C mcmc_amd/csrc`" % path
+        )
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, res, args in _SIGS:
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,238 @@
+// mhlik_kernels.hpp -- CDNA4 (gfx950) device code of the MH likelihood path.
+//
+// One streaming pass over the HBM-resident design matrix replaces the
+// reference's cublas{D,S}gemv + reduceRegr2 + reduce2 passes + D2H tail sum
+// (src/mcmc_gpu/mcmc_gpu.cu:177-257, src/reduction/reduction_kernel.cu:140-280):
+//
+//   tile kernel   : each 256-thread workgroup owns one row tile.  Every lane
+//                   holds VEC adjacent rows per 16-byte load (2 doubles /
+//                   4 floats), so a wave reads 1 KiB contiguous per column.
+//                   Row dots accumulate column by column in the gslcblas
+//                   order; then -log(1+exp(.)) per row, a wave64 DPP
+//                   reduction, four wave sums through LDS, one partial per
+//                   tile.
+//   segment kernel: one workgroup per row segment adds that segment's tile
+//                   partials in a fixed order.
+//
+// Every sum has a fixed shape that depends only on (tile_rows, segments), not
+// on the grid, the GPU count or timing: results are bitwise reproducible.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mhlik {
+
+constexpr int kBlock = 256;      // threads per workgroup (4 waves)
+constexpr int kWave = 64;
+constexpr int kMaxKargCols = 256; // theta travels in the kernarg segment up to this many columns
+
+template <typename T> struct Vec16;
+template <> struct Vec16<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+  static constexpr int N = 2;
+};
+template <> struct Vec16<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+  static constexpr int N = 4;
+};
+
+// theta by value: it rides in the kernarg segment of the launch, so there is
+// no per-iteration H2D copy (the reference does one cudaMemcpy per call,
+// mcmc_gpu.cu:231).  Scalar loads fetch it; it never occupies VGPRs.
+template <typename T> struct ThetaArg {
+  T v[kMaxKargCols];
+};
+
+// Where a tile lives:  element (row r of tile t, column j) is at
+//   X[t * tile_stride + j * col_stride + r]
+// TILED:    tile_stride = tile_rows * d, col_stride = tile_rows
+// COLMAJOR: tile_stride = tile_rows,     col_stride = padded leading dimension
+struct TileGeom {
+  int64_t tile_stride;
+  int64_t col_stride;
+  int32_t d;
+};
+
+// ---------------------------------------------------------------- reductions
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double x)
+{
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave with DPP moves only (no LDS, no permute
+// network): row_shr 1,2,4,8 scans each 16-lane row, row_bcast:15 / :31 carry
+// the row totals across.  Lane 63 ends up with the wave total.  Lanes with no
+// source (or rows masked off) read 0.0 and add nothing.
+__device__ __forceinline__ double wave_sum_lane63(double v)
+{
+  v += dpp_f64<0x111, 0xf>(v); // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v); // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v); // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v); // row_shr:8
+  v += dpp_f64<0x142, 0xa>(v); // row_bcast:15 -> rows 1,3
+  v += dpp_f64<0x143, 0xc>(v); // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// Workgroup sum: wave totals staged through LDS, added in wave order by
+// thread 0.  Returns the total in thread 0 (other threads: unspecified).
+__device__ __forceinline__ double block_sum(double v, double *lds /* kBlock/kWave doubles */)
+{
+  v = wave_sum_lane63(v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == kWave - 1) lds[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; w++) s += lds[w];
+  }
+  return s;
+}
+
+// ------------------------------------------------------------ per-row math
+
+// -log(1 + exp(x)) exactly as the reference writes it (mcmc_cpu.c:440,
+// reduction_kernel.cu:150): it overflows to -inf for x > 709.78 (double) /
+// 88.7 (float) like the reference does; no "stable softplus" rewrite.
+__device__ __forceinline__ double neg_log1pexp(double x) { return -log(1.0 + exp(x)); }
+__device__ __forceinline__ float neg_log1pexp(float x) { return -logf(1.0f + expf(x)); }
+
+// acc + t*x with the product rounded before the add (double: gslcblas on
+// baseline x86-64 has no FMA, and the row dots must match it bit for bit);
+// float: a fused chain, which is also what the f32 matrix cores compute.
+__device__ __forceinline__ double madd(double acc, double t, double x)
+{
+#pragma clang fp contract(off)
+  const double p = t * x;
+  return acc + p;
+}
+__device__ __forceinline__ float madd(float acc, float t, float x) { return fmaf(t, x, acc); }
+
+template <typename T, bool NT> __device__ __forceinline__ typename Vec16<T>::type load16(const T *p)
+{
+  typedef typename Vec16<T>::type V;
+  if constexpr (NT)
+    return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+  else
+    return *reinterpret_cast<const V *>(p);
+}
+
+// ------------------------------------------------------------- tile kernel
+//
+// R row groups per lane (tile_rows = 256 * VEC * R), U columns in flight per
+// step: R*U independent 16-byte loads per lane are issued before the first
+// is consumed.  KARG: theta from the kernarg struct, else from `theta_g`.
+// ROWDOTS: also store the row dots (debug / mvout).
+template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
+__global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ X, TileGeom g,
+                                                          const int32_t *__restrict__ tile_valid,
+                                                          ThetaArg<T> theta_k, const T *__restrict__ theta_g,
+                                                          double *__restrict__ partials,
+                                                          T *__restrict__ rowdots)
+{
+  typedef typename Vec16<T>::type V;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int STEP = kBlock * VEC; // rows covered by one load of the whole workgroup
+  __shared__ double lds[kBlock / kWave];
+
+  const int64_t tile = blockIdx.x;
+  const int valid = tile_valid[tile];
+  const T *tbase = X + tile * g.tile_stride;  // wave-uniform
+  const uint32_t lane_row = threadIdx.x * VEC; // first of this lane's VEC rows in group 0
+  const int d = g.d;
+
+  T acc[R][VEC];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[r][k] = (T)0;
+
+  int j0 = 0;
+  for (; j0 + U <= d; j0 += U) {
+    V x[U][R];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const T *col = tbase + (int64_t)(j0 + u) * g.col_stride;
+#pragma unroll
+      for (int r = 0; r < R; r++) x[u][r] = load16<T, NT>(col + (lane_row + (uint32_t)(r * STEP)));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      T t;
+      if constexpr (KARG)
+        t = theta_k.v[j0 + u];
+      else
+        t = theta_g[j0 + u];
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc[r][k] = madd(acc[r][k], t, x[u][r][k]);
+    }
+  }
+  for (; j0 < d; j0++) { // d % U leftover columns
+    const T *col = tbase + (int64_t)j0 * g.col_stride;
+    T t;
+    if constexpr (KARG)
+      t = theta_k.v[j0];
+    else
+      t = theta_g[j0];
+    V x[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) x[r] = load16<T, NT>(col + (lane_row + (uint32_t)(r * STEP)));
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int k = 0; k < VEC; k++) acc[r][k] = madd(acc[r][k], t, x[r][k]);
+  }
+
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const int row = (int)lane_row + r * STEP + k;
+      if (row < valid) {
+        s += (double)neg_log1pexp(acc[r][k]);
+        if constexpr (ROWDOTS) rowdots[tile * (int64_t)(STEP * R) + row] = acc[r][k];
+      }
+    }
+  }
+
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) partials[tile] = s;
+}
+
+// ---------------------------------------------------------- segment kernel
+//
+// grid = local segments * nvec.  Workgroup (s, k) adds partials[k*pstride +
+// t] for the tiles t of segment s: lane i takes t = begin+i, begin+i+256, ...
+// in order, then the fixed block tree.  The per-segment totals go to
+// out[k*out_stride + global_segment].
+struct SegDesc {
+  int64_t tile_begin;
+  int64_t tile_count;
+  int32_t global_index;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(kBlock) void segment_sum_kernel(const double *__restrict__ partials, int64_t pstride,
+                                                             const SegDesc *__restrict__ segs, int nseg_local,
+                                                             double *__restrict__ out, int out_stride)
+{
+  __shared__ double lds[kBlock / kWave];
+  const int s = blockIdx.x % nseg_local, k = blockIdx.x / nseg_local;
+  const SegDesc sd = segs[s];
+  const double *p = partials + (int64_t)k * pstride + sd.tile_begin;
+  double v = 0.0;
+  for (int64_t t = threadIdx.x; t < sd.tile_count; t += kBlock) v += p[t];
+  v = block_sum(v, lds);
+  if (threadIdx.x == 0) out[(int64_t)k * out_stride + sd.global_index] = v;
+}
+
+} // namespace mhlik

@@ -1,0 +1,187 @@
+"""Host-side mirror of the likelihood context (include/mhlik.h).
+
+`Likelihood` owns one `mhlik_ctx`: the design matrix resident in HBM and the
+kernels that evaluate  L(theta) = -sum_i log(1 + exp(x_i . theta))  on it,
+replacing the reference's gpu_likelihood_d / gpu_likelihood_f / mp_likelihood
+(src/mcmc_gpu/mcmc_gpu.cu:214, src/mcmc_gpu_sp/mcmc_gpu_sp.cu:216,
+src/mcmc_mp/mcmc_mp.cu:475).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+F64, F32 = 1, 2
+LAYOUT_DEFAULT, LAYOUT_TILED, LAYOUT_COLMAJOR = 0, 1, 2
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Likelihood:
+    def __init__(self, n_rows, n_cols, precision=F64, device=-1, rank=0, world=1, segments=0,
+                 layout=LAYOUT_DEFAULT, variant=0, timing=False):
+        self._lib = L.load_mhlik()
+        self._ctx = C.c_void_p()
+        cfg = L.Config()
+        cfg.n_rows, cfg.n_cols, cfg.precision, cfg.device = int(n_rows), int(n_cols), int(precision), int(device)
+        cfg.rank, cfg.world, cfg.segments = int(rank), int(world), int(segments)
+        cfg.layout, cfg.variant, cfg.timing = int(layout), int(variant), int(bool(timing))
+        rc = self._lib.mhlik_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            raise L.MhlikError(rc, (self._lib.mhlik_last_error(None) or b"").decode())
+        self.n_rows, self.n_cols, self.precision = int(n_rows), int(n_cols), int(precision)
+        self.rank, self.world = int(rank), int(world)
+        self.segments = int(segments) if segments else 8
+        b, n = C.c_int64(), C.c_int64()
+        self._chk(self._lib.mhlik_local_rows(self._ctx, C.byref(b), C.byref(n)))
+        self.local_begin, self.local_rows = b.value, n.value
+
+    # -- plumbing ---------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise L.MhlikError(rc, (self._lib.mhlik_last_error(self._ctx) or b"").decode())
+
+    @property
+    def handle(self):
+        """The raw mhlik_ctx* (for the C samplers)."""
+        return self._ctx
+
+    def close(self):
+        if self._ctx:
+            self._lib.mhlik_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ---------------------------------------------------------------
+    def upload(self, X, row0=0):
+        """X: Fortran-ordered (column-major) array [rows, d]; row 0 of X is
+        global row `row0` (data_util.c:33 layout: X[i, j] = -y_i * x_ij)."""
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[1] != self.n_cols:
+            raise ValueError("X must be [rows, %d]" % self.n_cols)
+        if not X.flags.f_contiguous:
+            X = np.asfortranarray(X)
+        ld = X.shape[0]
+        if X.dtype == np.float64:
+            self._chk(self._lib.mhlik_upload_f64(self._ctx, _ptr(X), ld, row0))
+        elif X.dtype == np.float32:
+            self._chk(self._lib.mhlik_upload_f32(self._ctx, _ptr(X), ld, row0))
+        else:
+            raise TypeError("X must be float64 or float32")
+
+    def fill_synthetic(self, seed):
+        self._chk(self._lib.mhlik_fill_synthetic(self._ctx, int(seed)))
+
+    def download(self, dtype=np.float64):
+        X = np.empty((self.local_rows, self.n_cols), dtype=dtype, order="F")
+        ld = max(self.local_rows, 1)
+        if dtype == np.float64:
+            self._chk(self._lib.mhlik_download_f64(self._ctx, _ptr(X), ld))
+        else:
+            self._chk(self._lib.mhlik_download_f32(self._ctx, _ptr(X), ld))
+        return X
+
+    # -- evaluation ---------------------------------------------------------
+    def loglik(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.shape != (self.n_cols,):
+            raise ValueError("theta must have %d entries" % self.n_cols)
+        out = C.c_double()
+        self._chk(self._lib.mhlik_loglik_f64(self._ctx, _ptr(th), C.byref(out)))
+        return out.value
+
+    def loglik_f32(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float32)
+        if th.shape != (self.n_cols,):
+            raise ValueError("theta must have %d entries" % self.n_cols)
+        out = C.c_float()
+        self._chk(self._lib.mhlik_loglik_f32(self._ctx, _ptr(th), C.byref(out)))
+        return out.value
+
+    def loglik_batched(self, Theta, dtype=np.float64):
+        Th = np.ascontiguousarray(Theta, dtype=dtype)
+        if Th.ndim != 2 or Th.shape[1] != self.n_cols:
+            raise ValueError("Theta must be [K, %d]" % self.n_cols)
+        out = np.empty(Th.shape[0], dtype=np.float64)
+        fn = self._lib.mhlik_loglik_batched_f64 if dtype == np.float64 else self._lib.mhlik_loglik_batched_f32
+        self._chk(fn(self._ctx, _ptr(Th), Th.shape[0], _ptr(out)))
+        return out
+
+    def rowdots(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        out = np.empty(self.local_rows, dtype=np.float64)
+        self._chk(self._lib.mhlik_rowdots_f64(self._ctx, _ptr(th), _ptr(out)))
+        return out
+
+    def segment_sums(self):
+        out = np.zeros(self.segments, dtype=np.float64)
+        self._chk(self._lib.mhlik_last_segment_sums(self._ctx, _ptr(out)))
+        return out
+
+    # -- mixed precision ----------------------------------------------------
+    def mp_reset(self, block_rows, blocks):
+        self._chk(self._lib.mhlik_mp_reset(self._ctx, int(block_rows), int(blocks)))
+
+    def mp_loglik(self, theta, block_rows, blocks, resamp_factor, resamp_choose, u_seed, u_call, bound_eps):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        st = L.MpState(int(block_rows), int(blocks), int(resamp_factor), int(resamp_choose), int(u_seed), int(u_call),
+                       float(bound_eps))
+        out, nb, nd = C.c_double(), C.c_int32(), C.c_int32()
+        self._chk(self._lib.mhlik_mp_loglik(self._ctx, C.byref(st), _ptr(th), C.byref(out), C.byref(nb), C.byref(nd)))
+        return out.value, nb.value, nd.value
+
+    def mp_bound(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        s, e = C.c_double(), C.c_double()
+        self._chk(self._lib.mhlik_mp_bound(self._ctx, _ptr(th), C.byref(s), C.byref(e)))
+        return s.value, e.value
+
+    # -- multi GPU ------------------------------------------------------------
+    @staticmethod
+    def make_comm_id():
+        lib = L.load_mhlik()
+        buf = (C.c_uint8 * L.COMM_ID_BYTES)()
+        rc = lib.mhlik_comm_make_id(buf)
+        if rc != 0:
+            raise L.MhlikError(rc, (lib.mhlik_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, comm_id):
+        buf = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._chk(self._lib.mhlik_comm_init(self._ctx, buf))
+
+    # -- instrumentation ----------------------------------------------------------
+    def last_kernel(self):
+        ms, nbytes = C.c_float(), C.c_int64()
+        self._chk(self._lib.mhlik_last_kernel_ms(self._ctx, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def info(self):
+        inf = L.Info()
+        self._chk(self._lib.mhlik_get_info(self._ctx, C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in L.Info._fields_ if k != "reserved"}
+
+
+def synthetic_host(seed, n_rows, n_cols, row0=0, rows=None):
+    """Host copy of the seeded synthetic data set (same bits as the device fill)."""
+    lib = L.load_mhlik()
+    rows = n_rows - row0 if rows is None else rows
+    X = np.empty((rows, n_cols), dtype=np.float64, order="F")
+    rc = lib.mhlik_synthetic_host_f64(int(seed), int(n_rows), int(n_cols), int(row0), int(rows), _ptr(X), max(rows, 1))
+    if rc != 0:
+        raise L.MhlikError(rc, "mhlik_synthetic_host_f64: bad arguments")
+    return X
