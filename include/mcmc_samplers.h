@@ -1,0 +1,112 @@
+/*
+ * mcmc_samplers.h -- the sampler / tuner entry points of libmcmc_amd.so.
+ *
+ * Same names, argument lists and by-value structs as the reference
+ * (src/mcmc_gpu/mcmc_gpu.h:16-49, src/mcmc_gpu_sp/mcmc_gpu_sp.h:16-51,
+ * src/mcmc_mp/mcmc_mp.h:18-52), so its host drivers (src/(all)/(all)_host.c,
+ * tests/(all).c) link against this library unchanged.  They stay in C; the
+ * per-iteration likelihood goes through the C-ABI in mhlik.h to hand-written
+ * HIP kernels.
+ *
+ * The reference's inner helpers carry CUDA types in their signatures
+ * (cublasHandle_t, curandGenerator_t, dev_v_str: mcmc_gpu.h:19-42).  Those are
+ * implementation detail there and do not exist here; their roles are taken by
+ * the functions at the bottom, which take an mhlik_ctx* instead.
+ */
+#ifndef MCMC_AMD_SAMPLERS_H
+#define MCMC_AMD_SAMPLERS_H
+
+#include "mcmc_types.h"
+#include "mhlik.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- double precision: src/mcmc_gpu/mcmc_gpu.h -------------------------- */
+void gpu_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata, gpu_v_str gpu,
+                 out_str *res);                                                             /* :16 */
+void tune_ess_gpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, gpu_v_str gpu, double *initCond,
+                  int length);                                                              /* :32 */
+void tune_target_a_gpu_v2(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, gpu_v_str gpu,
+                          double *initCond, double ratio, int max_reps);                    /* :33 */
+void tune_target_a_gpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, gpu_v_str gpu,
+                       double *initCond, int length);                                       /* :35 */
+double acceptance_ratio_gpu(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, double plhood); /* :45 */
+double log_prior_gpu(double *sample, mcmc_str mcin);                                        /* :47 */
+void print_gpu_info(void);                                                                  /* :49 */
+
+/* ---- single precision: src/mcmc_gpu_sp/mcmc_gpu_sp.h -------------------- */
+void sp_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata, gpu_v_str gpu,
+                out_str *res);                                                              /* :16 */
+void tune_ess_sp(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, gpu_v_str gpu, float *initCond,
+                 int length);                                                               /* :35 */
+void tune_target_a_sp_v2(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, gpu_v_str gpu,
+                         float *initCond, float ratio, int max_reps);                       /* :37 */
+float acceptance_ratio_sp(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, float plhood); /* :49 */
+float log_prior_sp(float *sample, mcmc_str mcin);                                           /* :51 */
+
+/* ---- mixed precision: src/mcmc_mp/mcmc_mp.h ------------------------------ */
+void mp_sampler(data_str data, gsl_rng *r, mp_str *mpVar, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata,
+                double lhoodBound, out_str *res);                                           /* :18 */
+double acceptance_ratio_mp(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, double plhood); /* :37 */
+double log_prior_mp(double *sample, mcmc_str mcin);                                         /* :38 */
+double get_lowerbound(data_str data, double *initialCond, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct); /* :41 */
+void get_blockSz(data_str data, gsl_rng *r, mp_str *mpVar, mcmc_str mcin, mcmc_tune_str mct, double *initialCond,
+                 double lhoodBound);                                                        /* :48 */
+
+/* ---- chain statistics used by the tuners and drivers:
+ *      src/util/processing_util.h (circular_autocorrelation, get_ess, ...) ---- */
+double circular_autocorrelation(double *out_v, double *in_m, int data_dim, int samples, int lag_idx);
+float circular_autocorrelation_sp(float *out_v, float *in_m, int data_dim, int samples, int lag_idx);
+double get_ess(double *samples, int sample_sz, int sample_dim, int max_lag, double *autocorrelation_v);
+float get_ess_sp(float *samples, int sample_sz, int sample_dim, int max_lag, float *autocorrelation_v);
+void calculate_normalised_sample_means(mcmc_v_str mcdata, mcmc_str mcin);
+void calculate_normalised_sample_means_sp(mcmc_v_str mcdata, mcmc_str mcin);
+
+/* ---- RNG set-up: src/util/alloc_util.h ----------------------------------- */
+void init_rng(gsl_rng **r);
+void init_rng_seed(gsl_rng **r, unsigned long int seed);
+void free_rng(gsl_rng *r);
+
+/* ======================================================================== *
+ *  Not in the reference                                                    *
+ * ======================================================================== */
+
+/* Inner loops with the CUDA handles replaced by the likelihood context
+ * (roles of metropolis_gpu / burn_in_metropolis_gpu / gpu_likelihood_d,
+ * mcmc_gpu.h:19-29). */
+void metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata,
+                    mcmc_int_v mclocv, mcmc_int *mcloc, int *accepted_samples, out_str *res);
+void burn_in_metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata,
+                            mcmc_int_v mclocv, mcmc_int *mcloc);
+double gpu_likelihood_d(mhlik_ctx *lik, mcmc_str mcin, double *samples, out_str *res);
+float gpu_likelihood_f(mhlik_ctx *lik, mcmc_str mcin, float *samplesf, out_str *res);
+
+/* By default every sampler / tuner call uploads data.data (or data.dataf) to
+ * a fresh context and frees it on return, as the reference does
+ * (mcmc_gpu.cu:53-58, 78-81).  A context attached here is used instead by
+ * every following call whose (Nd, ddata) match it: upload once, share between
+ * tuner and sampler, use device-generated data, or run row-sharded over
+ * several GPUs.  Pass NULL to detach.  The caller keeps ownership. */
+void mcmc_amd_attach_context(mhlik_ctx *lik);
+mhlik_ctx *mcmc_amd_attached_context(void);
+
+/* Per-iteration record of the MH loops (every loop appends while tracing). */
+typedef struct {
+  double lik;   /* L(theta') */
+  double ratio; /* log acceptance ratio (MP: the ratio itself) */
+  double logu;  /* log(u) (MP: u) */
+  int accept;
+} mcmc_amd_trace_rec;
+void mcmc_amd_trace_begin(mcmc_amd_trace_rec *buf, long capacity);
+long mcmc_amd_trace_end(void);
+
+/* Progress lines on stdout like the reference's (default on = 1). */
+void mcmc_amd_set_verbose(int on);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MCMC_AMD_SAMPLERS_H */

@@ -184,6 +184,10 @@ int mhlik_last_kernel_ms(const mhlik_ctx *ctx, float *ms, int64_t *bytes);
 
 /* Geometry actually used (for DESIGN.md / bench reporting). */
 typedef struct mhlik_info {
+  int64_t n_rows; /* global rows, columns and precision mask of the config */
+  int32_t n_cols;
+  int32_t precision;
+  int32_t rank, world;
   int64_t local_rows;
   int64_t tiles_f64, tiles_f32;
   int32_t tile_rows_f64, tile_rows_f32;

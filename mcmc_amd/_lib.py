@@ -34,6 +34,11 @@ class Config(C.Structure):
 
 class Info(C.Structure):
     _fields_ = [
+        ("n_rows", C.c_int64),
+        ("n_cols", C.c_int32),
+        ("precision", C.c_int32),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
         ("local_rows", C.c_int64),
         ("tiles_f64", C.c_int64),
         ("tiles_f32", C.c_int64),
@@ -110,7 +115,7 @@ def load_mhlik():
             "mcmc_amd: %s not found -- the MI355X likelihood path has no CPU fallback; "
             "build it with `make -C mcmc_amd/csrc`" % path
         )
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, res, args in _SIGS:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res

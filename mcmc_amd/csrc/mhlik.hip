@@ -186,7 +186,7 @@ const VariantDef kVariants[] = {
     {8, 2, true},   // 12
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 2;
+constexpr int kDefaultVariant = 1;
 
 template <typename T> Store &store_of(mhlik_ctx *c);
 template <> Store &store_of<double>(mhlik_ctx *c) { return c->s64; }
@@ -708,6 +708,11 @@ int mhlik_get_info(const mhlik_ctx *c, mhlik_info *info)
 {
   if (!c || !info) return MHLIK_EINVAL;
   memset(info, 0, sizeof *info);
+  info->n_rows = c->cfg.n_rows;
+  info->n_cols = c->cfg.n_cols;
+  info->precision = c->cfg.precision;
+  info->rank = c->cfg.rank;
+  info->world = c->cfg.world;
   info->local_rows = c->local_rows;
   info->tiles_f64 = c->s64.ntiles;
   info->tiles_f32 = c->s32.ntiles;

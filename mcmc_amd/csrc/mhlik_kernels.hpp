@@ -129,6 +129,39 @@ template <typename T, bool NT> __device__ __forceinline__ typename Vec16<T>::typ
 // step: R*U independent 16-byte loads per lane are issued before the first
 // is consumed.  KARG: theta from the kernarg struct, else from `theta_g`.
 // ROWDOTS: also store the row dots (debug / mvout).
+
+// Columns [j0, j0+U) of one tile: issue all loads, then accumulate in column
+// order.  Columns are always consumed in increasing j, whatever U is, so the
+// row dots do not depend on the unroll factor.
+template <typename T, int R, int U, bool NT, bool KARG>
+__device__ __forceinline__ void tile_columns(const T *__restrict__ tbase, int64_t col_stride, uint32_t lane_row,
+                                             int j0, const ThetaArg<T> &theta_k, const T *__restrict__ theta_g,
+                                             T (&acc)[R][Vec16<T>::N])
+{
+  typedef typename Vec16<T>::type V;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int STEP = kBlock * VEC;
+  V x[U][R];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const T *col = tbase + (int64_t)(j0 + u) * col_stride;
+#pragma unroll
+    for (int r = 0; r < R; r++) x[u][r] = load16<T, NT>(col + (lane_row + (uint32_t)(r * STEP)));
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    T t;
+    if constexpr (KARG)
+      t = theta_k.v[j0 + u];
+    else
+      t = theta_g[j0 + u];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int k = 0; k < VEC; k++) acc[r][k] = madd(acc[r][k], t, x[u][r][k]);
+  }
+}
+
 template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
 __global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ X, TileGeom g,
                                                           const int32_t *__restrict__ tile_valid,
@@ -136,14 +169,13 @@ __global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ 
                                                           double *__restrict__ partials,
                                                           T *__restrict__ rowdots)
 {
-  typedef typename Vec16<T>::type V;
   constexpr int VEC = Vec16<T>::N;
   constexpr int STEP = kBlock * VEC; // rows covered by one load of the whole workgroup
   __shared__ double lds[kBlock / kWave];
 
   const int64_t tile = blockIdx.x;
   const int valid = tile_valid[tile];
-  const T *tbase = X + tile * g.tile_stride;  // wave-uniform
+  const T *tbase = X + tile * g.tile_stride;   // wave-uniform
   const uint32_t lane_row = threadIdx.x * VEC; // first of this lane's VEC rows in group 0
   const int d = g.d;
 
@@ -154,42 +186,18 @@ __global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ 
     for (int k = 0; k < VEC; k++) acc[r][k] = (T)0;
 
   int j0 = 0;
-  for (; j0 + U <= d; j0 += U) {
-    V x[U][R];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const T *col = tbase + (int64_t)(j0 + u) * g.col_stride;
-#pragma unroll
-      for (int r = 0; r < R; r++) x[u][r] = load16<T, NT>(col + (lane_row + (uint32_t)(r * STEP)));
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      T t;
-      if constexpr (KARG)
-        t = theta_k.v[j0 + u];
-      else
-        t = theta_g[j0 + u];
-#pragma unroll
-      for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int k = 0; k < VEC; k++) acc[r][k] = madd(acc[r][k], t, x[u][r][k]);
-    }
-  }
-  for (; j0 < d; j0++) { // d % U leftover columns
-    const T *col = tbase + (int64_t)j0 * g.col_stride;
-    T t;
-    if constexpr (KARG)
-      t = theta_k.v[j0];
-    else
-      t = theta_g[j0];
-    V x[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) x[r] = load16<T, NT>(col + (lane_row + (uint32_t)(r * STEP)));
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-      for (int k = 0; k < VEC; k++) acc[r][k] = madd(acc[r][k], t, x[r][k]);
-  }
+  for (; j0 + U <= d; j0 += U) tile_columns<T, R, U, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc);
+  // d % U leftover columns: halve the batch until nothing is left
+  if constexpr (U >= 32)
+    if (j0 + 16 <= d) { tile_columns<T, R, 16, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 16; }
+  if constexpr (U >= 16)
+    if (j0 + 8 <= d) { tile_columns<T, R, 8, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 8; }
+  if constexpr (U >= 8)
+    if (j0 + 4 <= d) { tile_columns<T, R, 4, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 4; }
+  if constexpr (U >= 4)
+    if (j0 + 2 <= d) { tile_columns<T, R, 2, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 2; }
+  if constexpr (U >= 2)
+    if (j0 + 1 <= d) { tile_columns<T, R, 1, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 1; }
 
   double s = 0.0;
 #pragma unroll

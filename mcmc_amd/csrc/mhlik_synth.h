@@ -60,4 +60,13 @@ MHLIK_HD int32_t mhlik_synth_label(uint64_t seed, int64_t row, int32_t d)
   return acc < 0.0 ? -1 : 1;
 }
 
+/* uniform in [0,1) for (seed, call, block): the per-data-block uniforms of the
+ * mixed-precision path (reference: a cuRAND stream, mcmc_mp.cu:507) */
+MHLIK_HD double mhlik_mp_uniform(uint64_t seed, uint64_t call, uint64_t block)
+{
+  uint64_t h = mhlik_mix64(mhlik_mix64(seed ^ 0xA0761D6478BD642FULL) + call);
+  h = mhlik_mix64(h + block);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
 #endif

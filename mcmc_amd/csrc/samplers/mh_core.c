@@ -1,0 +1,187 @@
+/*
+ * mh_core.c -- see mh_core.h.
+ */
+#include "mh_core.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+int mcmc_amd_verbose = 1;
+void mcmc_amd_set_verbose(int on) { mcmc_amd_verbose = on; }
+
+static mhlik_ctx *g_attached = NULL;
+void mcmc_amd_attach_context(mhlik_ctx *lik) { g_attached = lik; }
+mhlik_ctx *mcmc_amd_attached_context(void) { return g_attached; }
+
+static mcmc_amd_trace_rec *g_trace = NULL;
+static long g_trace_cap = 0, g_trace_n = 0;
+
+void mcmc_amd_trace_begin(mcmc_amd_trace_rec *buf, long capacity)
+{
+  g_trace = buf;
+  g_trace_cap = capacity;
+  g_trace_n = 0;
+}
+
+long mcmc_amd_trace_end(void)
+{
+  long n = g_trace_n;
+  g_trace = NULL;
+  g_trace_cap = g_trace_n = 0;
+  return n;
+}
+
+void mh_trace_push(double lik, double ratio, double logu, int accept)
+{
+  if (!g_trace) return;
+  if (g_trace_n < g_trace_cap) {
+    mcmc_amd_trace_rec *t = &g_trace[g_trace_n];
+    t->lik = lik;
+    t->ratio = ratio;
+    t->logu = logu;
+    t->accept = accept;
+  }
+  g_trace_n++;
+}
+
+void mh_check(int status, mhlik_ctx *lik, const char *file, int line)
+{
+  if (status == MHLIK_OK) return;
+  fprintf(stderr, "GPUassert: %s %s %d\n", mhlik_last_error(lik), file, line);
+  exit(status);
+}
+
+mhlik_ctx *mh_acquire(data_str data, mcmc_str mcin, int precision, int *owned)
+{
+  *owned = 0;
+  if (g_attached) {
+    mhlik_info info;
+    /* the attached context is used when its shape matches this call */
+    if (mhlik_get_info(g_attached, &info) == MHLIK_OK && info.n_rows == (int64_t)mcin.Nd &&
+        info.n_cols == mcin.ddata && (info.precision & precision) == precision)
+      return g_attached;
+  }
+  mhlik_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.n_rows = mcin.Nd;
+  cfg.n_cols = mcin.ddata;
+  cfg.precision = precision;
+  cfg.device = 0; /* the reference pins device 0 (mcmc_gpu.cu:28) */
+  cfg.world = 1;
+  cfg.timing = 1; /* out_str carries per-call kernel times (mcmc_gpu.cu:248-254) */
+  mhlik_ctx *lik = NULL;
+  int rc = mhlik_create(&cfg, &lik);
+  if (rc != MHLIK_OK) {
+    fprintf(stderr, "GPUassert: %s %s %d\n", mhlik_last_error(NULL), __FILE__, __LINE__);
+    exit(rc);
+  }
+  if (precision & MHLIK_F64) {
+    if (!data.data) {
+      fprintf(stderr, "ERROR: data.data is NULL and no context is attached.\n");
+      exit(MHLIK_EINVAL);
+    }
+    MH_CHECK(mhlik_upload_f64(lik, data.data, mcin.Nd, 0), lik);
+  }
+  if (precision & MHLIK_F32) {
+    if (!data.dataf) {
+      fprintf(stderr, "ERROR: data.dataf is NULL and no context is attached.\n");
+      exit(MHLIK_EINVAL);
+    }
+    MH_CHECK(mhlik_upload_f32(lik, data.dataf, mcin.Nd, 0), lik);
+  }
+  *owned = 1;
+  return lik;
+}
+
+void mh_release(mhlik_ctx *lik, int owned)
+{
+  if (owned) mhlik_destroy(lik);
+}
+
+void mh_alloc_vectors(mcmc_int_v *v, int d, int want_double, int want_float)
+{
+  v->proposed = v->current = NULL;
+  v->proposedf = v->currentf = NULL;
+  if (want_double) {
+    v->proposed = (double *)calloc((size_t)d, sizeof(double));
+    v->current = (double *)calloc((size_t)d, sizeof(double));
+    if (!v->proposed || !v->current) fprintf(stderr, "ERROR: MH work vectors did not allocate.\n");
+  }
+  if (want_float) {
+    v->proposedf = (float *)calloc((size_t)d, sizeof(float));
+    v->currentf = (float *)calloc((size_t)d, sizeof(float));
+    if (!v->proposedf || !v->currentf) fprintf(stderr, "ERROR: MH float work vectors did not allocate.\n");
+  }
+}
+
+void mh_free_vectors(mcmc_int_v v)
+{
+  free(v.proposed);
+  free(v.current);
+  free(v.proposedf);
+  free(v.currentf);
+}
+
+/* sum_j log N(theta_j; 0, prior_sd) -- mcmc_gpu.cu:648-658, mcmc_mp.cu:638-648 */
+double mh_log_prior_d(const double *sample, int d, int prior_sd)
+{
+  double log_prob = 0;
+  for (int k = 0; k < d; k++) log_prob += log(gsl_ran_gaussian_pdf(sample[k], prior_sd));
+  return log_prob;
+}
+
+/* The loop body of mcmc_gpu.cu:101-128 (and its burn-in / short-run twins,
+ * :150-173, :580-599, :612-636; MP: mcmc_mp.cu:384-416). */
+int mh_step_d(mh_lik_d lik, void *env, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc,
+              out_str *res, int prior_sd, int exp_rule)
+{
+  const int d = mcin.ddata;
+  for (int k = 0; k < d; k++) {
+    v.proposed[k] = v.current[k] + gsl_ran_gaussian_ziggurat(r, sd);
+    if (v.proposedf) v.proposedf[k] = (float)v.proposed[k]; /* mcmc_mp.cu:390 */
+  }
+
+  const double plhood = lik(env, mcin, v, res);
+
+  loc->pposterior = mh_log_prior_d(v.proposed, d, prior_sd) + plhood;
+  const double log_ratio = loc->pposterior - loc->cposterior;
+  int accept;
+  if (exp_rule) {
+    loc->acceptance = exp(log_ratio); /* acceptance_ratio_mp, mcmc_mp.cu:635 */
+    loc->u = gsl_rng_uniform(r);
+    accept = (loc->u <= loc->acceptance); /* mcmc_mp.cu:402 */
+    mh_trace_push(plhood, loc->acceptance, loc->u, accept);
+  } else {
+    loc->acceptance = log_ratio;
+    loc->u = gsl_rng_uniform(r);
+    const double logu = log(loc->u);
+    accept = (logu <= loc->acceptance); /* mcmc_gpu.cu:114 */
+    mh_trace_push(plhood, loc->acceptance, logu, accept);
+  }
+  if (accept) {
+    for (int k = 0; k < d; k++) v.current[k] = v.proposed[k];
+    if (v.currentf)
+      for (int k = 0; k < d; k++) v.currentf[k] = (float)v.current[k];
+    loc->cposterior = loc->pposterior;
+  }
+  return accept;
+}
+
+/* ---- RNG set-up: src/util/alloc_util.c:249-277 ---- */
+void init_rng(gsl_rng **r)
+{
+  gsl_rng_env_setup();
+  *r = gsl_rng_alloc(gsl_rng_default);
+  if (*r == NULL) fprintf(stderr, "ERROR: RNG Allocation did not complete successfully!\n");
+}
+
+void init_rng_seed(gsl_rng **r, unsigned long int seed)
+{
+  gsl_rng_default_seed = seed;
+  gsl_rng_env_setup();
+  *r = gsl_rng_alloc(gsl_rng_default);
+  if (*r == NULL) fprintf(stderr, "ERROR: RNG Allocation did not complete successfully!\n");
+}
+
+void free_rng(gsl_rng *r) { gsl_rng_free(r); }

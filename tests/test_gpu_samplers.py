@@ -1,0 +1,107 @@
+"""The C samplers on the MI355X vs the CPU oracle: with seeded proposals the
+DP sampler must reproduce the oracle's accept/reject sequence and samples
+(BASELINE.json north_star; compare_cpu_gpu-shaped, but re-seeded before each
+run -- tests/compare_cpu_gpu.c:96-105 continues one RNG stream instead)."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_DP = 1e-10
+REL_TOL_SP = 1e-4
+
+
+@pytest.mark.parametrize("N,d,seed", [(10000, 3, 0), (10000, 3, 1), (10000, 16, 2), (50000, 16, 0), (3000, 64, 1)])
+def test_gpu_sampler_trace_equals_cpu_sampler(N, d, seed):
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(12345, N, d)
+    Ns, burnin, rwsd = 300, 100, 2.38 / np.sqrt(d) * 0.05
+    ref = O.cpu_sampler(X, seed, Ns, burnin, rwsd)
+    got = S.gpu_sampler(X, seed, Ns, burnin, rwsd)
+    assert len(ref["trace"]) == len(got["trace"]) == Ns + burnin - 1
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"]), "accept/reject sequence differs"
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert np.array_equal(ref["burn"], got["burn"])
+    rel = np.abs(ref["trace"]["lik"] - got["trace"]["lik"]) / np.abs(ref["trace"]["lik"])
+    assert rel.max() <= REL_TOL_DP
+    assert ref["acceptance"] == got["acceptance"]
+    # the decision margin says how close any iteration came to flipping
+    margin = np.abs(ref["trace"]["logu"] - ref["trace"]["ratio"]).min()
+    assert margin > 1e-9
+
+
+def test_tuner_matches_oracle():
+    import ctypes as C
+
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 5000, 3
+    X = synthetic_host(12345, N, d)
+    L = O.lib()
+    mvout = np.empty(N)
+    data = O.data_str(data=O.ptr(X).value, mvout=O.ptr(mvout).value)
+    mcin = O.mcmc_str(ddata=d, Nd=N, Ns=1, burnin=50, impl=0)
+    mct = O.mcmc_tune_str(rwsd=2.38 / np.sqrt(d), rwsdf=0)
+    init = np.zeros(d)
+    rng = O.Rng(7, L)
+    L.tune_target_a_cpu_v2(data, rng.r, mcin, C.byref(mct), O.ptr(init), 0.25, 4)
+    got = S.tune_target_a_gpu_v2(X, 7, 50, 2.38 / np.sqrt(d), 0.25, 4)
+    assert got == mct.rwsd
+
+
+def test_attached_context_and_device_data():
+    from mcmc_amd import Likelihood, samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 20000, 8
+    X = synthetic_host(4242, N, d)
+    ref = O.cpu_sampler(X, 3, 100, 20, 0.02)
+    with Likelihood(N, d, timing=True) as lk:
+        lk.fill_synthetic(4242)
+        with S.attached(lk):
+            got = S.gpu_sampler(None, 3, 100, 20, 0.02, n_rows=N, n_cols=d)
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"])
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert got["res"].kernelTime > 0
+
+
+def test_sp_likelihood_within_1e4_of_dp_and_reference_order():
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    for N, d in [(10000, 3), (200000, 16), (65536, 64)]:
+        X = synthetic_host(12345, N, d)
+        Xf = np.asfortranarray(X.astype(np.float32))
+        rng = np.random.default_rng(1)
+        with Likelihood(N, d, precision=2) as lk:
+            lk.upload(Xf)
+            for _ in range(3):
+                th = rng.normal(0, 0.3, d)
+                dp, _ = O.log_likelihood(X, th)
+                got = lk.loglik_f32(th.astype(np.float32))
+                assert abs(got - dp) <= REL_TOL_SP * abs(dp)
+                L = O.lib()
+                scratch = np.empty(N, dtype=np.float32)
+                thf = th.astype(np.float32)
+                ref_sp = L.oracle_gpu_likelihood_f(O.ptr(Xf), N, d, N, O.ptr(thf), O.ptr(scratch), 256, 32)
+                assert abs(got - ref_sp) <= REL_TOL_SP * abs(ref_sp)
+
+
+def test_sp_sampler_runs_and_agrees_statistically():
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 20000, 3
+    X = synthetic_host(12345, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    dp = S.gpu_sampler(X, 5, 2000, 500, 0.05, trace=False)
+    sp = S.sp_sampler(Xf, 5, 2000, 500, 0.05, trace=False)
+    assert 0.02 < sp["acceptance"] < 0.98
+    m_dp, m_sp = dp["samples"].mean(0), sp["samples"].mean(0)
+    s_dp = dp["samples"].std(0)
+    assert np.all(np.abs(m_dp - m_sp) < 3 * s_dp + 0.05)
