@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- MH iterations/s and likelihood GB/s (% of HBM peak) at
+N=10M, d=64 (BASELINE.json), on 1/2/4/8 MI355X.
+
+A "step" is one Metropolis-Hastings iteration of the C sampler loop
+(metropolis_gpu: d ziggurat draws, one double-precision likelihood pass over
+the HBM-resident design matrix, prior, one uniform, accept test).  With
+--gpus G > 1 the SAME N rows are sharded over the G ranks (strong scaling) and
+every iteration's per-segment partial sums are all-reduced over RCCL.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus G --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--cols", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--data-seed", type=int, default=12345)
+    ap.add_argument("--cpu-iters", type=int, default=60, help="MH iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the SP / multi-core side measurements")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from mcmc_amd import Likelihood, F64, F32
+    from mcmc_amd import samplers as S
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    N, d = a.rows, a.cols
+    lk = Likelihood(N, d, precision=F64, device=local_rank, rank=rank, world=world, timing=True)
+    lk.fill_synthetic(a.data_seed)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        lk.comm_init(bytes(idt.cpu().numpy().tobytes()))
+
+    lib = S.load_samplers()
+    P = C.c_void_p
+    lib.burn_in_metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P]
+    lib.metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P,
+                                   C.POINTER(C.c_int), C.POINTER(S.out_str)]
+
+    K, W = a.steps, a.warmup
+    burn_len = max(W, 1)  # burn-in does 1 + (burnin-1) = W likelihood evaluations
+    samples = np.zeros((K, d))
+    burn = np.zeros((burn_len, d))
+    mcin = S.mcmc_str(ddata=d, Nd=N, Ns=K, burnin=burn_len, impl=S.IMPL_GPU)
+    rwsd = 2.38 / np.sqrt(d) * 2e-3  # small random-walk step: the posterior at N=1e7 is narrow
+    mct = S.mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
+    mcdata = S.mcmc_v_str(samples=samples.ctypes.data, burn=burn.ctypes.data)
+    prop, cur = np.zeros(d), np.zeros(d)
+    mclocv = S.mcmc_int_v(proposed=prop.ctypes.data, current=cur.ctypes.data)
+    mcloc = S.mcmc_int()
+    res = S.out_str()
+    accepted = C.c_int(0)
+    rng = S.Rng(a.seed)  # same seed on every rank: identical proposals and decisions everywhere
+    trace = np.zeros(K + burn_len + 8, dtype=S.TRACE_DTYPE)
+
+    # warm-up: W untimed iterations (burn-in loop of the sampler)
+    lib.burn_in_metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc))
+    lib.mcmc_amd_trace_begin(trace.ctypes.data_as(P), len(trace))
+    barrier()
+    t0 = time.perf_counter()
+    lib.metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc), C.byref(accepted), C.byref(res))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ntrace = lib.mcmc_amd_trace_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(res.kernelTime)  # mean device time of the streaming kernel over the K timed steps (HIP events)
+    info = lk.info()
+    local_bytes = info["local_rows"] * d * 8
+    achieved = local_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    traffic = pmc_traffic(N, d, info["local_rows"])
+    out = {
+        "metric": "mh_iterations_per_sec",
+        "value": K / elapsed,
+        "unit": "it/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "Bayesian logistic regression MH, N=%d d=%d DP (BASELINE configs[2])" % (N, d),
+                   "rows": N, "cols": d, "rows_per_gpu": info["local_rows"],
+                   "parallelism": "rows sharded over %d GPU(s), per-iteration RCCL all-reduce" % world
+                   if world > 1 else "single GPU"},
+        "likelihood_GBps_whole_job": N * d * 8 / (elapsed / K) / 1e9,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "lik_tile_kernel<double>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": local_bytes},
+        "acceptance": accepted.value / K,
+    }
+
+    # ---- side measurements on rank 0 of a single-GPU run ----------------------------------
+    if world == 1 and rank == 0:
+        if not a.no_extras:
+            out["extra"] = extras(a, lk, S, np, N, d)
+        if a.cpu_iters > 0:
+            out["cpu_baseline"] = cpu_baseline(a, np, N, d, rwsd, lk, S)
+    lk.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pmc_traffic(N, d, local_rows):
+    """HBM bytes per launch of the streaming kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).
+    Counters cannot be read from inside this process; the passes were run on
+    this same command (profiles/r01_bench_pmc_hbm_traffic.json).  null when
+    the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm_traffic.json")
+    try:
+        prof = json.load(open(path))
+    except OSError:
+        return None
+    w = prof.get("workload", {})
+    if w.get("rows") != N or w.get("cols") != d or local_rows != N:
+        return None
+    for name, k in prof.get("kernels", {}).items():
+        if "lik_tile_kernel<double" in name:
+            return k.get("hbm_bytes_per_launch_corrected")
+    return None
+
+
+def extras(a, lk, S, np, N, d):
+    """SP twin of the workload (BASELINE configs[2] is 'SP vs DP')."""
+    from mcmc_amd import Likelihood, F32
+
+    ex = {}
+    K = min(a.steps, 200)
+    with Likelihood(N, d, precision=F32, timing=True) as lf:
+        lf.fill_synthetic(a.data_seed)
+        with S.attached(lf):
+            t0 = time.perf_counter()
+            r = S.sp_sampler(None, a.seed, K, 2, 2.38 / np.sqrt(d) * 2e-3, trace=False, n_rows=N, n_cols=d)
+            el = time.perf_counter() - t0
+        kms = float(r["res"].kernelTime)
+        ex["sp"] = {"it_per_s": (K + 2) / el, "kernel_ms": kms,
+                    "GBps": N * d * 4 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                    "frac_hbm_peak": N * d * 4 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms > 0 else 0.0}
+        th = np.random.default_rng(3).normal(0, 0.01, d)
+        dp = lk.loglik(th)
+        sp = lf.loglik_f32(th.astype(np.float32))
+        ex["sp"]["rel_diff_vs_dp"] = abs(sp - dp) / abs(dp)
+    return ex
+
+
+def cpu_baseline(a, np, N, d, rwsd, lk, S):
+    """The oracle's cpu_sampler (restated mcmc_cpu, 1 thread like the
+    reference) on a bounded sample of the SAME workload: the same N x d data,
+    a short seeded chain.  The same short chain is run on the GPU and the two
+    traces are compared (accept/reject sequence, log-likelihoods)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(a.data_seed, N, d)
+    iters, burn = a.cpu_iters, 2
+    t0 = time.perf_counter()
+    r = O.cpu_sampler(X, a.seed, iters, burn, rwsd)
+    el = time.perf_counter() - t0
+    evals = iters + burn  # likelihood evaluations = MH iterations incl. the chain start
+    with S.attached(lk):
+        g = S.gpu_sampler(None, a.seed, iters, burn, rwsd, n_rows=N, n_cols=d)
+    ct, gt = r["trace"], g["trace"]
+    rel = np.abs(ct["lik"] - gt["lik"]) / np.abs(ct["lik"])
+    L = O.lib()
+    th = np.zeros(d)
+    ncores = min(os.cpu_count() or 1, 16)
+    t1 = time.perf_counter()
+    L.oracle_log_likelihood_mt(O.ptr(th), O.ptr(X), N, d, N, ncores)
+    mt = time.perf_counter() - t1
+    return {"value": evals / el, "unit": "it/s", "cores": 1, "kind": "port",
+            "sample": "%d MH iterations (%d sampling + %d burn-in) of the oracle cpu_sampler at the full "
+                      "N=%d d=%d, same data and chain seed" % (evals, iters, burn, N, d),
+            "seconds": el,
+            "parity": {"iterations_compared": int(len(ct)),
+                       "accept_trace_equal": bool(np.array_equal(ct["accept"], gt["accept"])),
+                       "samples_equal": bool(np.array_equal(r["samples"], g["samples"])),
+                       "max_rel_loglik_diff": float(rel.max()) if len(rel) else None,
+                       "min_decision_margin": float(np.abs(ct["logu"] - ct["ratio"]).min()) if len(rel) else None},
+            "all_cores": {"it_per_s_likelihood_only": 1.0 / mt, "cores": ncores}}
+
+
+if __name__ == "__main__":
+    main()

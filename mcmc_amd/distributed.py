@@ -1,0 +1,103 @@
+"""Row-sharded likelihood over several GPUs, one process per GPU.
+
+The reference is single-GPU (cudaSetDevice(0) everywhere, mcmc_gpu.cu:28); the
+sharding is new.  L(theta) is a sum over rows, so the N rows are cut into
+`segments` fixed, contiguous row segments (8 by default); rank r of `world`
+holds segments [r*segments/world, (r+1)*segments/world).  Each evaluation
+produces one partial sum per segment; the per-segment sums of all ranks are
+all-reduced (a rank contributes zeros for segments it does not hold, so the
+all-reduce is exact) and added in segment order.  The result therefore has
+the same bits for every world size that divides `segments`, on every rank.
+
+Two transports:
+  "rccl"  -- the all-reduce runs inside libmhlik.so on the context's stream
+             (ncclAllReduce over xGMI); torch.distributed is used once, to
+             ship the 128-byte communicator id.  This is the bench path.
+  "torch" -- the segment sums go through torch.distributed.all_reduce on
+             whatever backend the group uses (gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def segment_rows(n_rows, segments=8):
+    """[(begin, rows)] of the fixed row segments (same rule as mhlik_create)."""
+    per = (n_rows + segments - 1) // segments
+    out = []
+    for g in range(segments):
+        b = min(g * per, n_rows)
+        e = min((g + 1) * per, n_rows)
+        out.append((b, e - b))
+    return out
+
+
+def shard_rows(n_rows, rank, world, segments=8):
+    """(first global row, row count, [segment indices]) held by `rank`."""
+    if segments % world != 0:
+        raise ValueError("segments=%d must be a multiple of world=%d" % (segments, world))
+    per = segments // world
+    segs = list(range(rank * per, (rank + 1) * per))
+    rows = segment_rows(n_rows, segments)
+    begin = rows[segs[0]][0]
+    count = sum(rows[g][1] for g in segs)
+    return begin, count, segs
+
+
+def combine_segment_sums(slots):
+    """Add the all-reduced per-segment sums in segment order (fixed order =>
+    identical bits on every rank and for every world size)."""
+    total = 0.0
+    for v in slots:
+        total += float(v)
+    return total
+
+
+class ShardedLikelihood:
+    """L(theta) over rows sharded across the ranks of a torch.distributed group."""
+
+    def __init__(self, n_rows, n_cols, precision=1, segments=8, transport="rccl", group=None, device=None,
+                 local_factory=None, **kw):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.segments = segments
+        self.transport = transport if self.world > 1 else "none"
+        self.begin, self.rows, self.segs = shard_rows(n_rows, self.rank, self.world, segments)
+        if local_factory is None:
+            from .likelihood import Likelihood
+
+            local_factory = Likelihood
+        self.local = local_factory(n_rows, n_cols, precision=precision, rank=self.rank, world=self.world,
+                                   segments=segments, device=-1 if device is None else device, **kw)
+        if self.transport == "rccl":
+            self._init_rccl()
+
+    def _init_rccl(self):
+        """Rank 0 makes the RCCL id; torch.distributed ships the bytes."""
+        from .likelihood import Likelihood
+
+        box = [Likelihood.make_comm_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        self.local.comm_init(box[0])
+
+    def _reduce_slots(self, slots):
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(slots, dtype=np.float64))
+        backend = self.dist.get_backend(self.group)
+        if backend == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def loglik(self, theta):
+        v = self.local.loglik(theta)
+        if self.transport in ("rccl", "none"):
+            return v  # already the sum over all shards
+        slots = self._reduce_slots(self.local.segment_sums())
+        return combine_segment_sums(slots)
+
+    def close(self):
+        self.local.close()

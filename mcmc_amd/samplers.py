@@ -37,6 +37,15 @@ class mcmc_tune_str(C.Structure):
     _fields_ = [("rwsd", C.c_double), ("rwsdf", C.c_float)]
 
 
+class mcmc_int_v(C.Structure):
+    _fields_ = [("proposed", C.c_void_p), ("current", C.c_void_p), ("proposedf", C.c_void_p), ("currentf", C.c_void_p)]
+
+
+class mcmc_int(C.Structure):
+    _fields_ = [("cposterior", C.c_double), ("pposterior", C.c_double), ("acceptance", C.c_double), ("u", C.c_double),
+                ("cposteriorf", C.c_float), ("pposteriorf", C.c_float), ("acceptancef", C.c_float), ("uf", C.c_float)]
+
+
 class gpu_v_str(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("size", "threads", "blocks", "maxThreads", "maxBlocks", "kernel", "cpuThresh")]
 
