@@ -120,6 +120,9 @@ struct mhlik_ctx {
   double *slots_recv = nullptr; // device [MAX_BATCH * nseg]
   double *slots_host = nullptr; // pinned host [MAX_BATCH * nseg]
   double *slots_host_dev = nullptr; // device view of slots_host
+  unsigned long long *done_flag = nullptr;     // pinned host word the last kernel writes
+  unsigned long long *done_flag_dev = nullptr; // its device view
+  unsigned long long done_seq = 0;
   double *theta_dev = nullptr;  // device staging for d > kMaxKargCols and for batched Theta
   void *theta_pin = nullptr;    // pinned host staging
   size_t theta_cap = 0;
@@ -349,25 +352,66 @@ int ensure_theta_staging(mhlik_ctx *c, size_t bytes)
   return MHLIK_OK;
 }
 
+// Wait for the completion word the last kernel of an evaluation writes into
+// pinned host memory.  Polling a host word is a few microseconds cheaper per
+// MH iteration than hipStreamSynchronize; the stream is still queried now and
+// then so that a failed launch cannot spin forever.
+int wait_published(mhlik_ctx *c, unsigned long long seq)
+{
+  volatile unsigned long long *flag = c->done_flag;
+  for (unsigned long long spins = 0;; spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return MHLIK_OK;
+    if ((spins & 0xFFF) == 0xFFF) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return MHLIK_OK;
+        return fail(c, MHLIK_EHIP, "stream drained but the completion word was not written");
+      }
+      if (q != hipErrorNotReady) return fail(c, MHLIK_EHIP, "stream error while waiting: %s", hipGetErrorString(q));
+    }
+  }
+}
+
 // Add the per-segment sums of `nvec` results (tile partials -> segment slots
 // -> all shards -> host), leaving out[k] = sum over segments in index order.
 int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
 {
   const int nseg = c->nseg, nloc = (int)c->segs.size();
   const bool dist = (c->cfg.world > 1 && c->comm);
-  double *slots = dist ? c->slots_send : c->slots_host_dev;
-  if (nloc > 0)
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(nloc * nvec), dim3(kBlock), 0, c->stream, c->partials,
-                       (int64_t)s.ntiles, s.segs, nloc, slots, nseg);
+  const int jobs = nloc * nvec;
+  const bool one_group = jobs <= kSegWaves;
+  const unsigned long long seq = ++c->done_seq;
+  bool published = false;
   if (dist) {
+    const int grid = one_group ? 1 : (jobs + kSegWaves - 1) / kSegWaves;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
+                       s.segs, nloc, nvec, c->slots_send, nseg, (unsigned long long *)nullptr, 0ull);
     int rc = g_rccl.AllReduce(c->slots_send, c->slots_recv, (size_t)nvec * nseg, kNcclFloat64, kNcclSum, c->comm,
                               c->stream);
     if (rc != 0) return fail(c, MHLIK_ECOMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(rc));
-    HIPCHK(c, hipMemcpyAsync(c->slots_host, c->slots_recv, sizeof(double) * nvec * nseg, hipMemcpyDeviceToHost,
-                             c->stream));
+    hipLaunchKernelGGL(publish_slots_kernel, dim3(1), dim3(kWave), 0, c->stream, c->slots_recv, c->slots_host_dev,
+                       nvec * nseg, c->done_flag_dev, seq);
+    published = true;
+  } else if (one_group) {
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(1), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
+                       s.segs, nloc, nvec, c->slots_host_dev, nseg, c->done_flag_dev, seq);
+    published = true;
+  } else {
+    const int grid = (jobs + kSegWaves - 1) / kSegWaves;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
+                       s.segs, nloc, nvec, c->slots_host_dev, nseg, (unsigned long long *)nullptr, 0ull);
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->cfg.timing) HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  HIPCHK(c, hipGetLastError());
+  if (published) {
+    int rc = wait_published(c, seq);
+    if (rc) return rc;
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (c->cfg.timing) {
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  }
 
   c->last_seg_sums.assign(c->slots_host, c->slots_host + nseg);
   for (int k = 0; k < nvec; k++) {
@@ -555,14 +599,17 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
   c->local_rows = 0;
   for (const Segment &sg : c->segs) c->local_rows += sg.rows;
 
+  // room for the slots plus one completion word at the end
   const size_t slot_bytes = sizeof(double) * MHLIK_MAX_BATCH * nseg;
   CREATE_CHK(hipMalloc((void **)&c->slots_send, slot_bytes));
   CREATE_CHK(hipMalloc((void **)&c->slots_recv, slot_bytes));
   CREATE_CHK(hipMemset(c->slots_send, 0, slot_bytes));
   CREATE_CHK(hipMemset(c->slots_recv, 0, slot_bytes));
-  CREATE_CHK(hipHostMalloc((void **)&c->slots_host, slot_bytes, hipHostMallocMapped));
-  memset(c->slots_host, 0, slot_bytes);
+  CREATE_CHK(hipHostMalloc((void **)&c->slots_host, slot_bytes + 64, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->slots_host, 0, slot_bytes + 64);
   CREATE_CHK(hipHostGetDevicePointer((void **)&c->slots_host_dev, c->slots_host, 0));
+  c->done_flag = (unsigned long long *)(c->slots_host + (size_t)MHLIK_MAX_BATCH * nseg);
+  c->done_flag_dev = (unsigned long long *)(c->slots_host_dev + (size_t)MHLIK_MAX_BATCH * nseg);
 #undef CREATE_CHK
   *out = c;
   return MHLIK_OK;

@@ -1,3 +1,300 @@
-// mhlik_batched.hpp -- K-chain batched likelihood (X.Theta on the matrix cores).
+// mhlik_batched.hpp -- K proposals per pass: X.Theta on the CDNA4 matrix cores.
+//
+// No counterpart in the reference (one chain, one theta per likelihood call,
+// src/mcmc_gpu/mcmc_gpu.cu:101-107); BASELINE.json config 5.  With K = 64
+// proposals the pass does 2*K = 128 flop per matrix element instead of 2, which
+// moves it from the HBM roof to the MFMA roof (f32: 157 TF dense, f64: 78.6 TF).
+//
+// The design matrix is already in the layout an MFMA A-operand wants: inside a
+// tile it is column-major, so "one row per lane, one column per k" is a
+// coalesced read.  Each lane loads 16 bytes (4 floats / 2 doubles = VEC
+// adjacent rows of one column); element m of the load feeds the m-th of VEC
+// independent MFMA row sets.  Which physical row sits in which MFMA row does
+// not matter -- the result is summed over rows -- as long as the pad rows of a
+// ragged tile can be identified, which the C-layout formula below does.
+// Theta (d x 64, zero padded) sits in LDS in B-operand order.
+//
+//   f32: v_mfma_f32_32x32x2_f32   A[i=l&31][k=l>>5], B[k=l>>5][n=l&31],
+//        C: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
+//        (bit-for-bit a k-ordered fmaf chain: the same row dots as the
+//        single-theta float kernel)
+//   f64: v_mfma_f64_16x16x4_f64   A[i=l&15][k=l>>4], B[k=l>>4][n=l&15],
+//        C: col = l&15, row = (l>>4) + 4*r, r in [0,4)
+//
+// Epilogue: -log(1+exp(.)) on every accumulator element, per-chain sum over
+// the tile's rows (registers -> LDS -> fixed order), one partial per (chain,
+// tile): partials[chain*pstride + tile], reduced by segment_sum_kernel.
 #pragma once
+
 #include "mhlik_kernels.hpp"
+
+namespace mhlik {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBatchCols = 64; // chains per pass (Theta is zero padded to this)
+
+// Fast float -log(1+exp(x)) on the hardware exp2/log2 units (v_exp_f32,
+// v_log_f32, ~1 ulp each).  Overflows to -inf above ~88.7 like expf does.
+__device__ __forceinline__ float neg_log1pexp_fast(float x)
+{
+  const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+  return -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);
+}
+
+// ------------------------------------------------------------------- f32
+// Workgroup = 256 threads = 4 waves; f32 tile = 1024 rows; wave w owns rows
+// [256w, 256w+256) in two passes of 128 rows (32 A-rows x 4 row sets).
+// NB = number of 32-chain blocks (1: K <= 32, 2: K <= 64).  KU = k-steps
+// (pairs of columns) whose loads are in flight together.
+// LDS: thetaL[(j*32 + c)*2 + n] = Theta[j][n*32 + c]  (float2 per (j, c)).
+template <int NB, int KU>
+__global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float *__restrict__ X, TileGeom g,
+                                                                    const int32_t *__restrict__ tile_valid,
+                                                                    const float *__restrict__ theta_dev, int d_pad,
+                                                                    double *__restrict__ partials, int64_t pstride,
+                                                                    int K)
+{
+  typedef Vec16<float>::type V4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *thetaL = reinterpret_cast<float *>(smem);                    // d_pad * 64 floats
+  double *red = reinterpret_cast<double *>(smem + (size_t)d_pad * kBatchCols * sizeof(float)); // [4 waves][NB][64 lanes]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int valid = tile_valid[tile];
+  const int d = g.d;
+
+  // stage Theta (already in B-operand order on the device) into LDS
+  for (int i = threadIdx.x * 4; i < d_pad * kBatchCols; i += kBlock * 4)
+    *reinterpret_cast<V4 *>(thetaL + i) = *reinterpret_cast<const V4 *>(theta_dev + i);
+  __syncthreads();
+
+  const int arow = lane & 31; // MFMA A-row supplied by this lane
+  const int kk = lane >> 5;   // which of the two columns of a k-step
+  const float *tbase = X + tile * g.tile_stride;
+  float sum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) sum[n] = 0.f;
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int row0 = wave * 256 + pass * 128; // first tile row of this pass
+    const float *rbase = tbase + row0 + 4 * arow;
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < NB; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    // software pipeline: the loads of batch b+1 are issued before the MFMAs of batch b
+    int j0 = 0;
+    const int nfull = d / (2 * KU);
+    V4 a[KU], an[KU];
+    if (nfull > 0) {
+#pragma unroll
+      for (int u = 0; u < KU; u++) an[u] = load16<float, true>(rbase + (int64_t)(2 * u + kk) * g.col_stride);
+    }
+    for (int bt = 0; bt < nfull; bt++, j0 += 2 * KU) {
+#pragma unroll
+      for (int u = 0; u < KU; u++) a[u] = an[u];
+      if (bt + 1 < nfull) {
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+          an[u] = load16<float, true>(rbase + (int64_t)(j0 + 2 * KU + 2 * u + kk) * g.col_stride);
+      }
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + ((j0 + 2 * u + kk) * 32 + arow) * 2);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    for (; j0 < d; j0 += 2) { // leftover k-steps; a column >= d contributes zeros
+      const int col = j0 + kk;
+      V4 a = {0.f, 0.f, 0.f, 0.f};
+      if (col < d) a = load16<float, true>(rbase + (int64_t)col * g.col_stride);
+      const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + (col * 32 + arow) * 2);
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+
+    // epilogue: accumulator (m, n, r) of lane l is tile row  row0 + 4*i + m  with
+    // i = (r&3) + 8*(r>>2) + 4*(l>>5), chain n*32 + (l&31)
+    if (row0 + 128 <= valid) {
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) sum[n] += neg_log1pexp_fast(acc[m][n][r]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * kk;
+          const bool ok = row0 + 4 * i + m < valid;
+#pragma unroll
+          for (int n = 0; n < NB; n++) sum[n] += ok ? neg_log1pexp_fast(acc[m][n][r]) : 0.f;
+        }
+    }
+  }
+
+  // per-chain sum over the workgroup: [wave][n][lane] -> thread per chain, fixed order
+#pragma unroll
+  for (int n = 0; n < NB; n++) red[(wave * NB + n) * 64 + lane] = (double)sum[n];
+  __syncthreads();
+  if ((int)threadIdx.x < NB * 32) {
+    const int n = threadIdx.x >> 5, c = threadIdx.x & 31;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s += red[(w * NB + n) * 64 + c] + red[(w * NB + n) * 64 + c + 32];
+    const int chain = n * 32 + c;
+    if (chain < K) partials[(int64_t)chain * pstride + tile] = s;
+  }
+}
+
+// ------------------------------------------------------------------- f64
+// f64 tile = 512 rows; wave w owns rows [128w, 128w+128) in two passes of 64
+// rows (16 A-rows x 4 row sets: two double2 loads per lane per k-step).
+// NB = number of 16-chain blocks (1..4).  One k-step = 4 columns.
+// LDS: thetaL[(j*16 + c)*4 + n] = Theta[j][n*16 + c]  (4 doubles per (j, c)).
+template <int NB, int KU>
+__global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double *__restrict__ X, TileGeom g,
+                                                                    const int32_t *__restrict__ tile_valid,
+                                                                    const double *__restrict__ theta_dev, int d_pad,
+                                                                    double *__restrict__ partials, int64_t pstride,
+                                                                    int K)
+{
+  typedef Vec16<double>::type V2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *thetaL = reinterpret_cast<double *>(smem);                  // d_pad * 64 doubles
+  double *red = thetaL + (size_t)d_pad * kBatchCols;                  // [4 waves][NB][64 lanes]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int valid = tile_valid[tile];
+  const int d = g.d;
+
+  for (int i = threadIdx.x * 2; i < d_pad * kBatchCols; i += kBlock * 2)
+    *reinterpret_cast<V2 *>(thetaL + i) = *reinterpret_cast<const V2 *>(theta_dev + i);
+  __syncthreads();
+
+  const int arow = lane & 15; // MFMA A-row supplied by this lane
+  const int kk = lane >> 4;   // which of the four columns of a k-step
+  const double *tbase = X + tile * g.tile_stride;
+  double sum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) sum[n] = 0.0;
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int row0 = wave * 128 + pass * 64;
+    const double *rbase = tbase + row0 + 2 * arow; // rows 2i, 2i+1 and 32+2i, 32+2i+1
+    f64x4 acc[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < NB; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[m][n][r] = 0.0;
+
+    int j0 = 0;
+    const int nfull = d / (4 * KU);
+    V2 a0[KU], a1[KU], n0[KU], n1[KU];
+    if (nfull > 0) {
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const double *col = rbase + (int64_t)(4 * u + kk) * g.col_stride;
+        n0[u] = load16<double, true>(col);
+        n1[u] = load16<double, true>(col + 32);
+      }
+    }
+    for (int bt = 0; bt < nfull; bt++, j0 += 4 * KU) {
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        a0[u] = n0[u];
+        a1[u] = n1[u];
+      }
+      if (bt + 1 < nfull) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+          const double *col = rbase + (int64_t)(j0 + 4 * KU + 4 * u + kk) * g.col_stride;
+          n0[u] = load16<double, true>(col);
+          n1[u] = load16<double, true>(col + 32);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const double *bp = thetaL + ((j0 + 4 * u + kk) * 16 + arow) * 4;
+        double b[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) b[n] = (n < NB) ? bp[n] : 0.0;
+#pragma unroll
+        for (int n = 0; n < NB; n++) {
+          acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u][0], b[n], acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u][1], b[n], acc[1][n], 0, 0, 0);
+          acc[2][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u][0], b[n], acc[2][n], 0, 0, 0);
+          acc[3][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u][1], b[n], acc[3][n], 0, 0, 0);
+        }
+      }
+    }
+    for (; j0 < d; j0 += 4) {
+      const int colj = j0 + kk;
+      V2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+      if (colj < d) {
+        const double *col = rbase + (int64_t)colj * g.col_stride;
+        a0 = load16<double, true>(col);
+        a1 = load16<double, true>(col + 32);
+      }
+      const double *bp = thetaL + (colj * 16 + arow) * 4;
+#pragma unroll
+      for (int n = 0; n < NB; n++) {
+        const double b = bp[n];
+        acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b, acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b, acc[1][n], 0, 0, 0);
+        acc[2][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b, acc[2][n], 0, 0, 0);
+        acc[3][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b, acc[3][n], 0, 0, 0);
+      }
+    }
+
+    // accumulator (m, n, r) of lane l: A-row i = (l>>4) + 4*r, chain n*16 + (l&15);
+    // tile row = row0 + (m>>1)*32 + 2*i + (m&1)
+    const bool full = row0 + 64 <= valid;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = kk + 4 * r;
+        const bool ok = full || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+          if (ok) sum[n] += neg_log1pexp(acc[m][n][r]);
+      }
+  }
+
+#pragma unroll
+  for (int n = 0; n < NB; n++) red[(wave * NB + n) * 64 + lane] = sum[n];
+  __syncthreads();
+  if ((int)threadIdx.x < NB * 16) {
+    const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) s += red[(w * NB + n) * 64 + c + 16 * q];
+    const int chain = n * 16 + c;
+    if (chain < K) partials[(int64_t)chain * pstride + tile] = s;
+  }
+}
+
+} // namespace mhlik

@@ -11,8 +11,9 @@
 //                   order; then -log(1+exp(.)) per row, a wave64 DPP
 //                   reduction, four wave sums through LDS, one partial per
 //                   tile.
-//   segment kernel: one workgroup per row segment adds that segment's tile
-//                   partials in a fixed order.
+//   segment kernel: one wave per row segment adds that segment's tile
+//                   partials in a fixed order and publishes the result to
+//                   pinned host memory with a completion word the host polls.
 //
 // Every sum has a fixed shape that depends only on (tile_rows, segments), not
 // on the grid, the GPU count or timing: results are bitwise reproducible.
@@ -229,18 +230,54 @@ struct SegDesc {
   int32_t pad;
 };
 
-__global__ __launch_bounds__(kBlock) void segment_sum_kernel(const double *__restrict__ partials, int64_t pstride,
-                                                             const SegDesc *__restrict__ segs, int nseg_local,
-                                                             double *__restrict__ out, int out_stride)
+constexpr int kSegBlock = 1024;                   // threads of the segment kernel
+constexpr int kSegWaves = kSegBlock / kWave;      // 16 jobs in flight per workgroup
+
+// Job (s, k) = (local segment s, result vector k): one WAVE adds
+// partials[k*pstride + t] over the tiles t of segment s -- lane i takes
+// t = begin+i, begin+i+64, ... in order, then the fixed DPP wave tree -- and
+// lane 63 stores out[k*out_stride + global_segment].  Jobs are dealt to the
+// waves of the grid round-robin; which wave runs a job does not change its
+// bits.  With a single workgroup (flag != nullptr) the kernel also publishes
+// completion: every storing lane fences its store to system scope, the
+// workgroup meets, thread 0 writes `seq` to *flag (pinned host memory the
+// host thread is polling).
+__global__ __launch_bounds__(kSegBlock) void segment_sum_kernel(const double *__restrict__ partials, int64_t pstride,
+                                                                const SegDesc *__restrict__ segs, int nseg_local,
+                                                                int nvec, double *__restrict__ out, int out_stride,
+                                                                unsigned long long *flag, unsigned long long seq)
 {
-  __shared__ double lds[kBlock / kWave];
-  const int s = blockIdx.x % nseg_local, k = blockIdx.x / nseg_local;
-  const SegDesc sd = segs[s];
-  const double *p = partials + (int64_t)k * pstride + sd.tile_begin;
-  double v = 0.0;
-  for (int64_t t = threadIdx.x; t < sd.tile_count; t += kBlock) v += p[t];
-  v = block_sum(v, lds);
-  if (threadIdx.x == 0) out[(int64_t)k * out_stride + sd.global_index] = v;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = blockIdx.x * kSegWaves + (threadIdx.x / kWave);
+  const int nwaves = gridDim.x * kSegWaves;
+  const int jobs = nseg_local * nvec;
+  for (int job = wave; job < jobs; job += nwaves) {
+    const int s = job % nseg_local, k = job / nseg_local;
+    const SegDesc sd = segs[s];
+    const double *p = partials + (int64_t)k * pstride + sd.tile_begin;
+    double v = 0.0;
+    for (int64_t t = lane; t < sd.tile_count; t += kWave) v += p[t];
+    v = wave_sum_lane63(v);
+    if (lane == kWave - 1) {
+      out[(int64_t)k * out_stride + sd.global_index] = v;
+      if (flag) __threadfence_system();
+    }
+  }
+  if (flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// After an all-reduce: copy the combined slots to pinned host memory and
+// publish completion (one wave).
+__global__ __launch_bounds__(kWave) void publish_slots_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                              int n, unsigned long long *flag, unsigned long long seq)
+{
+  for (int i = threadIdx.x; i < n; i += kWave) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 } // namespace mhlik

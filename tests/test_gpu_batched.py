@@ -1,0 +1,65 @@
+"""K proposals per pass (X.Theta on MFMA) vs the oracle's K separate
+log_likelihood calls.  No reference counterpart (BASELINE config 5)."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_batched(X, Theta):
+    return np.array([O.log_likelihood(X, th)[0] for th in Theta])
+
+
+@pytest.mark.parametrize("N,d,K", [(4096, 8, 64), (10000, 3, 5), (5000, 16, 33), (3000, 128, 64), (1025, 7, 1),
+                                   (20000, 64, 16), (513, 1, 64), (70001, 10, 48)])
+def test_batched_f64_matches_oracle(N, d, K):
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(12345, N, d)
+    Theta = np.random.default_rng(K).normal(0, 0.3, (K, d))
+    want = _oracle_batched(X, Theta)
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        got = lk.loglik_batched(Theta)
+        single = np.array([lk.loglik(th) for th in Theta[:4]])
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs(got - want).max()
+    assert np.all(np.abs(got[:4] - single) <= 1e-10 * np.abs(single))
+
+
+@pytest.mark.parametrize("N,d,K", [(4096, 8, 64), (10000, 3, 5), (5000, 16, 33), (3000, 128, 64), (1025, 7, 1),
+                                   (20000, 64, 16), (70001, 11, 48)])
+def test_batched_f32_within_sp_tolerance(N, d, K):
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(12345, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    Theta = np.random.default_rng(K).normal(0, 0.3, (K, d))
+    want = _oracle_batched(X, Theta)
+    with Likelihood(N, d, precision=2) as lk:
+        lk.upload(Xf)
+        got = lk.loglik_batched(Theta.astype(np.float32), dtype=np.float32)
+        single = np.array([lk.loglik_f32(th.astype(np.float32)) for th in Theta[:4]])
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want)), (np.abs(got - want) / np.abs(want)).max()
+    # same float row dots as the single-theta kernel; only the exp/log flavour differs
+    assert np.all(np.abs(got[:4] - single) <= 2e-6 * np.abs(single))
+
+
+def test_batched_overflow_column():
+    from mcmc_amd import Likelihood
+
+    N, d = 2000, 2
+    X = np.zeros((N, d), order="F")
+    X[:, 0] = 1.0
+    X[:, 1] = np.linspace(-1, 1, N)
+    Theta = np.array([[800.0, 0.0], [0.1, 0.2], [-800.0, 0.0]])
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        got = lk.loglik_batched(Theta)
+    want = _oracle_batched(X, Theta)
+    assert got[0] == want[0] == -np.inf
+    assert abs(got[1] - want[1]) <= 1e-10 * abs(want[1])
+    assert got[2] == want[2] == 0.0

@@ -1,7 +1,7 @@
 // tools/bench_variants.cpp -- sweep kernel variants / layouts of libmhlik on
 // one GPU and print likelihood-kernel time and GB/s.  Tuning aid only.
 //   build: g++ -O2 -Iinclude tools/bench_variants.cpp -Lmcmc_amd/lib -lmhlik -Wl,-rpath,'$ORIGIN/../mcmc_amd/lib' -o tools/bench_variants
-//   usage: bench_variants [N] [d] [reps] [precisions: 1|2|3] [variants "1,2,3" | all] [layouts "1,2"]
+//   usage: bench_variants [N] [d] [reps] [precisions: 1|2|3] [variants "1,2,3" | all] [layouts "1,2"] [timing 0|1]
 #include <algorithm>
 #include <math.h>
 #include <stdio.h>
@@ -38,6 +38,7 @@ int main(int argc, char **argv)
   int precs = argc > 4 ? atoi(argv[4]) : 3;
   std::vector<int> variants = parse_list(argc > 5 ? argv[5] : "all", 1, 12);
   std::vector<int> layouts = parse_list(argc > 6 ? argv[6] : "1,2", 1, 2);
+  int timing = argc > 7 ? atoi(argv[7]) : 1;
 
   std::vector<double> theta(d);
   std::vector<float> thetaf(d);
@@ -60,7 +61,7 @@ int main(int argc, char **argv)
         cfg.world = 1;
         cfg.layout = layout;
         cfg.variant = variant;
-        cfg.timing = 1;
+        cfg.timing = timing;
         mhlik_ctx *ctx = nullptr;
         if (mhlik_create(&cfg, &ctx)) {
           printf("create failed: %s\n", mhlik_last_error(nullptr));
@@ -91,6 +92,7 @@ int main(int argc, char **argv)
         std::sort(ms.begin(), ms.end());
         double bytes = (double)N * d * (prec == 1 ? 8 : 4);
         double mn = ms.front(), md = ms[ms.size() / 2];
+        if (!timing) mn = md = wall;
         printf("%d %d %2d  %8.4f %8.4f  %8.1f %8.1f  %5.1f%%  %8.4f  %.10g\n", prec, layout, variant, mn, md,
                bytes / mn * 1e-6, bytes / md * 1e-6, bytes / md * 1e-6 / 80.0, wall, prec == 1 ? L : (double)Lf);
         fflush(stdout);
