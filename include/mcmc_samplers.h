@@ -83,6 +83,13 @@ void burn_in_metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, mcmc_tune
 double gpu_likelihood_d(mhlik_ctx *lik, mcmc_str mcin, double *samples, out_str *res);
 float gpu_likelihood_f(mhlik_ctx *lik, mcmc_str mcin, float *samplesf, out_str *res);
 
+/* K independent DP chains in lock step, one batched (MFMA) likelihood pass per
+ * iteration.  r: K generators; samples [K][Ns][d]; burn [K][burnin][d] with
+ * row 0 of each chain its start; accepted [K]; use_f32 != 0 evaluates on the
+ * float matrix.  The context must hold the matching precision. */
+void mcmc_amd_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mcmc_str mcin, mcmc_tune_str mct,
+                                 double *samples, double *burn, int *accepted, int use_f32);
+
 /* By default every sampler / tuner call uploads data.data (or data.dataf) to
  * a fresh context and frees it on return, as the reference does
  * (mcmc_gpu.cu:53-58, 78-81).  A context attached here is used instead by

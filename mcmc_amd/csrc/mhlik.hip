@@ -379,27 +379,32 @@ int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
   const int nseg = c->nseg, nloc = (int)c->segs.size();
   const bool dist = (c->cfg.world > 1 && c->comm);
   const int jobs = nloc * nvec;
-  const bool one_group = jobs <= kSegWaves;
+  // which reduction shape: fixed by the data set's geometry alone (tiles per
+  // segment), never by the GPU count, so the bits stay world-invariant
+  const int64_t global_tiles_per_seg = ((c->cfg.n_rows + nseg - 1) / nseg + s.tile_rows - 1) / s.tile_rows;
+  const bool wide = global_tiles_per_seg > 8192;
+  const bool one_group = !wide && jobs <= kSegWaves;
   const unsigned long long seq = ++c->done_seq;
   bool published = false;
-  if (dist) {
+  double *seg_out = dist ? c->slots_send : c->slots_host_dev;
+  if (wide) {
+    hipLaunchKernelGGL(segment_sum_wide_kernel, dim3(jobs), dim3(kSegBlock), 0, c->stream, c->partials,
+                       (int64_t)s.ntiles, s.segs, nloc, seg_out, nseg);
+  } else {
     const int grid = one_group ? 1 : (jobs + kSegWaves - 1) / kSegWaves;
+    const bool flag = one_group && !dist;
     hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
-                       s.segs, nloc, nvec, c->slots_send, nseg, (unsigned long long *)nullptr, 0ull);
+                       s.segs, nloc, nvec, seg_out, nseg, flag ? c->done_flag_dev : (unsigned long long *)nullptr,
+                       flag ? seq : 0ull);
+    published = flag;
+  }
+  if (dist) {
     int rc = g_rccl.AllReduce(c->slots_send, c->slots_recv, (size_t)nvec * nseg, kNcclFloat64, kNcclSum, c->comm,
                               c->stream);
     if (rc != 0) return fail(c, MHLIK_ECOMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(rc));
     hipLaunchKernelGGL(publish_slots_kernel, dim3(1), dim3(kWave), 0, c->stream, c->slots_recv, c->slots_host_dev,
                        nvec * nseg, c->done_flag_dev, seq);
     published = true;
-  } else if (one_group) {
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(1), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
-                       s.segs, nloc, nvec, c->slots_host_dev, nseg, c->done_flag_dev, seq);
-    published = true;
-  } else {
-    const int grid = (jobs + kSegWaves - 1) / kSegWaves;
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
-                       s.segs, nloc, nvec, c->slots_host_dev, nseg, (unsigned long long *)nullptr, 0ull);
   }
   HIPCHK(c, hipGetLastError());
   if (published) {

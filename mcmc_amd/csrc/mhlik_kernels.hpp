@@ -230,6 +230,25 @@ struct SegDesc {
   int32_t pad;
 };
 
+// p[first] + p[first+STRIDE] + ... (< count), added in that order.  Eight loads
+// are put in flight together; slots past the end contribute +0.0, which leaves
+// the running sum's bits alone.
+template <int STRIDE> __device__ __forceinline__ double strided_sum(const double *__restrict__ p, int first, int64_t count)
+{
+  double v = 0.0;
+  for (int64_t t = first; t < count; t += (int64_t)STRIDE * 8) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t i = t + (int64_t)u * STRIDE;
+      x[u] = i < count ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) v += x[u];
+  }
+  return v;
+}
+
 constexpr int kSegBlock = 1024;                   // threads of the segment kernel
 constexpr int kSegWaves = kSegBlock / kWave;      // 16 jobs in flight per workgroup
 
@@ -255,9 +274,8 @@ __global__ __launch_bounds__(kSegBlock) void segment_sum_kernel(const double *__
     const int s = job % nseg_local, k = job / nseg_local;
     const SegDesc sd = segs[s];
     const double *p = partials + (int64_t)k * pstride + sd.tile_begin;
-    double v = 0.0;
-    for (int64_t t = lane; t < sd.tile_count; t += kWave) v += p[t];
-    v = wave_sum_lane63(v);
+    const double v0 = strided_sum<kWave>(p, lane, sd.tile_count);
+    const double v = wave_sum_lane63(v0);
     if (lane == kWave - 1) {
       out[(int64_t)k * out_stride + sd.global_index] = v;
       if (flag) __threadfence_system();
@@ -266,6 +284,32 @@ __global__ __launch_bounds__(kSegBlock) void segment_sum_kernel(const double *__
   if (flag) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// The same sum for segments with many tiles (N ~ 1e8): one 1024-thread
+// workgroup per job -- thread i takes t = begin+i, begin+i+1024, ... in order,
+// DPP wave tree, the 16 wave totals through LDS in wave order.  No completion
+// word (several workgroups): the host waits on the stream.
+__global__ __launch_bounds__(kSegBlock) void segment_sum_wide_kernel(const double *__restrict__ partials,
+                                                                     int64_t pstride,
+                                                                     const SegDesc *__restrict__ segs, int nseg_local,
+                                                                     double *__restrict__ out, int out_stride)
+{
+  __shared__ double lds[kSegWaves];
+  const int job = blockIdx.x;
+  const int s = job % nseg_local, k = job / nseg_local;
+  const SegDesc sd = segs[s];
+  const double *p = partials + (int64_t)k * pstride + sd.tile_begin;
+  double v = strided_sum<kSegBlock>(p, threadIdx.x, sd.tile_count);
+  v = wave_sum_lane63(v);
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1) lds[threadIdx.x / kWave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kSegWaves; w++) tot += lds[w];
+    out[(int64_t)k * out_stride + sd.global_index] = tot;
   }
 }
 

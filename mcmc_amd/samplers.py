@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "calculate_normalised_sample_means", "calculate_normalised_sample_means_sp", "init_rng", "init_rng_seed",
     "free_rng", "metropolis_gpu", "burn_in_metropolis_gpu", "gpu_likelihood_d", "gpu_likelihood_f",
     "mcmc_amd_attach_context", "mcmc_amd_attached_context", "mcmc_amd_trace_begin", "mcmc_amd_trace_end",
-    "mcmc_amd_set_verbose",
+    "mcmc_amd_set_verbose", "mcmc_amd_multichain_sampler",
 ]
 
 
@@ -253,6 +253,24 @@ def tune_target_a_gpu_v2(X, seed, burnin, rwsd, ratio=0.25, max_reps=40, rng=Non
     rng = rng or Rng(seed)
     S.tune_target_a_gpu_v2(data, rng.r, mcin, C.byref(mct), gpu_v_str(), _ptr(init), ratio, max_reps)
     return mct.rwsd
+
+
+def multichain_sampler(lik, seeds, Ns, burnin, rwsd, use_f32=False):
+    """K lock-step chains on an existing Likelihood context (batched MFMA pass
+    per iteration); chain k uses its own generator seeded seeds[k]."""
+    S = load_samplers()
+    K, d = len(seeds), lik.n_cols
+    rngs = [Rng(s) for s in seeds]
+    arr = (C.c_void_p * K)(*[r.r for r in rngs])
+    samples = np.zeros((K, Ns, d))
+    burn = np.zeros((K, max(burnin, 1), d))
+    acc = np.zeros(K, dtype=np.int32)
+    mcin = mcmc_str(ddata=d, Nd=lik.n_rows, Ns=Ns, burnin=burnin, impl=IMPL_GPU)
+    S.mcmc_amd_multichain_sampler.argtypes = [C.c_void_p, C.c_int, C.c_void_p, mcmc_str, mcmc_tune_str, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int]
+    S.mcmc_amd_multichain_sampler(lik.handle, K, arr, mcin, mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd), _ptr(samples),
+                                  _ptr(burn), _ptr(acc), int(use_f32))
+    return dict(samples=samples, burn=burn, accepted=acc)
 
 
 def get_ess(samples, max_lag):

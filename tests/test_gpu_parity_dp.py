@@ -99,3 +99,21 @@ def test_deterministic_and_segment_invariant():
         for s in segs:
             tot += s
         assert tot == a
+
+
+def test_many_tiles_uses_wide_segment_sum():
+    """More than 8192 tiles per segment switches the segment reduction to one
+    workgroup per segment (N ~ 1e8 shapes); same tolerance, still deterministic."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 8 * 8193 * 512 + 77, 2
+    X = synthetic_host(3, N, d)
+    th = np.array([0.3, -0.2])
+    want, _ = O.log_likelihood(X, th)
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        a = lk.loglik(th)
+        b = lk.loglik(th)
+    assert a == b
+    assert abs(a - want) <= REL_TOL_DP * abs(want)

@@ -105,3 +105,48 @@ def test_sp_sampler_runs_and_agrees_statistically():
     m_dp, m_sp = dp["samples"].mean(0), sp["samples"].mean(0)
     s_dp = dp["samples"].std(0)
     assert np.all(np.abs(m_dp - m_sp) < 3 * s_dp + 0.05)
+
+
+def test_config2_shape_compare_cpu_gpu_trace():
+    """BASELINE configs[1]: N=1M, d=16 DP, accept/reject parity (tests/compare_cpu_gpu.c shape,
+    with the RNG re-seeded before each run)."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 1_000_000, 16
+    X = synthetic_host(12345, N, d)
+    Ns, burnin, rwsd = 150, 50, 2.38 / np.sqrt(d) * 5e-3
+    ref = O.cpu_sampler(X, 0, Ns, burnin, rwsd)
+    got = S.gpu_sampler(X, 0, Ns, burnin, rwsd)
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"])
+    assert np.array_equal(ref["samples"], got["samples"])
+    rel = np.abs(ref["trace"]["lik"] - got["trace"]["lik"]) / np.abs(ref["trace"]["lik"])
+    assert rel.max() <= REL_TOL_DP
+    assert 0.05 < got["acceptance"] < 0.95
+
+
+def test_config1_shape_repeated_runs_share_one_stream():
+    """BASELINE configs[0] (tests/multiple_runs_cpu.c:56-71): back-to-back sampler runs on one
+    data set with the RNG state carried across runs; GPU and CPU agree run for run."""
+    from mcmc_amd import Likelihood, samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 10000, 3
+    X = synthetic_host(12345, N, d)
+    rng_cpu, rng_gpu = O.Rng(0), S.Rng(0)
+    import ctypes as C
+
+    L = O.lib()
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        with S.attached(lk):
+            for run in range(4):
+                g = S.gpu_sampler(X, None, 120, 30, 0.08, rng=rng_gpu)
+                mvout = np.empty(N)
+                samples, burn = np.zeros((120, d)), np.zeros((30, d))
+                res = O.out_str()
+                L.cpu_sampler(O.data_str(data=O.ptr(X).value, mvout=O.ptr(mvout).value), rng_cpu.r,
+                              O.mcmc_str(ddata=d, Nd=N, Ns=120, burnin=30), O.mcmc_tune_str(rwsd=0.08),
+                              O.mcmc_v_str(samples=O.ptr(samples).value, burn=O.ptr(burn).value), C.byref(res))
+                assert np.array_equal(samples, g["samples"]), run
+                assert res.acceptance == g["acceptance"]
