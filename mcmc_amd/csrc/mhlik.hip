@@ -377,7 +377,7 @@ int wait_published(mhlik_ctx *c, unsigned long long seq)
 int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
 {
   const int nseg = c->nseg, nloc = (int)c->segs.size();
-  const bool dist = (c->cfg.world > 1 && c->comm);
+  const bool dist = c->comm != nullptr;
   const int jobs = nloc * nvec;
   // which reduction shape: fixed by the data set's geometry alone (tiles per
   // segment), never by the GPU count, so the bits stay world-invariant
@@ -793,7 +793,11 @@ int mhlik_comm_init(mhlik_ctx *c, const uint8_t id[MHLIK_COMM_ID_BYTES])
 {
   if (!c) return MHLIK_EINVAL;
   if (!id) return fail(c, MHLIK_EINVAL, "id must not be NULL");
-  if (c->cfg.world <= 1) return MHLIK_OK;
+  // A one-rank communicator is pointless in production and skipped, unless
+  // MHLIK_FORCE_COMM=1 asks for it: that lets a single-GPU box exercise the
+  // whole RCCL path (dlopen, id, init, all-reduce on the stream, publish).
+  const char *force = getenv("MHLIK_FORCE_COMM");
+  if (c->cfg.world <= 1 && !(force && force[0] == '1')) return MHLIK_OK;
   std::string err;
   if (!rccl_load(err)) return fail(c, MHLIK_ECOMM, "%s", err.c_str());
   HIPCHK(c, hipSetDevice(c->device));

@@ -62,3 +62,25 @@ def test_sharded_hip_equals_single_context_bitwise(world):
         lk.fill_synthetic(SEED)
         for v in got[0][1]:
             assert lk.loglik(rng.normal(0, 0.05, D)) == v
+
+
+def test_rccl_path_with_one_rank(monkeypatch):
+    """The in-library RCCL transport on the one GPU of the box: a 1-rank
+    communicator (MHLIK_FORCE_COMM=1) runs the same code as N ranks do --
+    dlopen of librccl, id, ncclCommInitRank, ncclAllReduce on the context's
+    stream, publish kernel -- and must not change a bit of the result."""
+    from mcmc_amd import Likelihood
+
+    n, d = 300_000, 16
+    rng = np.random.default_rng(1)
+    ths = [rng.normal(0, 0.05, d) for _ in range(3)]
+    with Likelihood(n, d, device=0) as lk:
+        lk.fill_synthetic(SEED)
+        plain = [lk.loglik(t) for t in ths]
+        plain_b = lk.loglik_batched(np.array(ths))
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    with Likelihood(n, d, device=0) as lk:
+        lk.fill_synthetic(SEED)
+        lk.comm_init(Likelihood.make_comm_id())
+        assert [lk.loglik(t) for t in ths] == plain
+        assert np.array_equal(lk.loglik_batched(np.array(ths)), plain_b)
