@@ -163,6 +163,62 @@ int mhlik_mp_loglik(mhlik_ctx *ctx, const mhlik_mp_state *st, const double *thet
  * extreme of epsilon_i = sigma_D - sigma_S over all rows. */
 int mhlik_mp_bound(mhlik_ctx *ctx, const double *theta, double *sum_lb, double *epsilon);
 
+/* ---- MH chain kept on the device -----------
+ *
+ * Replaces the per-iteration host round trip of the reference's loop
+ * (metropolis_gpu, src/mcmc_gpu/mcmc_gpu.cu:101-128: H2D theta :231, D2H
+ * partials :205, CPU tail sum :207-209, prior + ratio :639-658, accept test
+ * :112-114; float twin src/mcmc_gpu_sp/mcmc_gpu_sp.cu:101-128).  The random
+ * numbers an iteration consumes do not depend on the chain (d Gaussians, then
+ * one uniform), so the C sampler draws them for a batch of iterations in the
+ * reference's order and the device runs the whole batch back to back:
+ *   proposed = current + increments[i]
+ *   L = likelihood(proposed);  pposterior = sum_j log N(proposed_j; 0, prior_sd) + L
+ *   accept iff log_u[i] <= pposterior - cposterior
+ * With world > 1 every rank calls with the same numbers; every rank ends with
+ * the same bits.  The _f32 twins keep state, prior sum, posterior and accept
+ * test in float like sp_sampler does. */
+typedef struct mhlik_chain_batch_f64 {
+  int64_t n;                /* iterations in this batch */
+  const double *increments; /* host [n][n_cols] */
+  const double *log_u;      /* host [n] */
+  double *samples;          /* host out [n][n_cols]: state after each iteration (NULL: skip) */
+  double *lik;              /* host out [n]: L(proposed) (NULL: skip) */
+  double *ratio;            /* host out [n]: pposterior - cposterior (NULL: skip) */
+  uint8_t *accepted;        /* host out [n]: 1 = accepted (NULL: skip) */
+  int64_t n_accepted;       /* out: accepted proposals of this batch */
+  float kernel_ms;          /* out: mean device time of the sampled likelihood kernels (config.timing) */
+  int32_t kernel_samples;   /* out: how many launches were bracketed with events */
+} mhlik_chain_batch_f64;
+
+typedef struct mhlik_chain_batch_f32 {
+  int64_t n;
+  const float *increments;
+  const float *log_u;
+  float *samples;
+  double *lik;
+  double *ratio;
+  uint8_t *accepted;
+  int64_t n_accepted;
+  float kernel_ms;
+  int32_t kernel_samples;
+} mhlik_chain_batch_f32;
+
+/* Start a chain at theta0: one likelihood pass, cposterior = prior + L(theta0)
+ * (start of burn_in_metropolis_gpu, mcmc_gpu.cu:141-147). */
+int mhlik_chain_begin_f64(mhlik_ctx *ctx, const double *theta0, double prior_sd, double *cposterior);
+int mhlik_chain_begin_f32(mhlik_ctx *ctx, const float *theta0, double prior_sd, float *cposterior);
+/* Continue from a state the caller holds (no likelihood pass). */
+int mhlik_chain_resume_f64(mhlik_ctx *ctx, const double *current, double cposterior, double prior_sd);
+int mhlik_chain_resume_f32(mhlik_ctx *ctx, const float *current, float cposterior, double prior_sd);
+/* Run batch->n iterations from the device-side state; blocks until the
+ * outputs are on the host. */
+int mhlik_chain_run_f64(mhlik_ctx *ctx, mhlik_chain_batch_f64 *batch);
+int mhlik_chain_run_f32(mhlik_ctx *ctx, mhlik_chain_batch_f32 *batch);
+/* Read the device-side state back. */
+int mhlik_chain_state_f64(mhlik_ctx *ctx, double *current, double *cposterior);
+int mhlik_chain_state_f32(mhlik_ctx *ctx, float *current, float *cposterior);
+
 /* ---- multi-GPU (no counterpart: the reference is single-GPU, mcmc_gpu.cu:28) */
 
 /* Rank 0 makes an id, the host layer ships the bytes to every rank (e.g. a

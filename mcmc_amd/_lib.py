@@ -64,6 +64,16 @@ class MpState(C.Structure):
     ]
 
 
+class ChainBatchF64(C.Structure):
+    _fields_ = [("n", C.c_int64), ("increments", C.c_void_p), ("log_u", C.c_void_p), ("samples", C.c_void_p),
+                ("lik", C.c_void_p), ("ratio", C.c_void_p), ("accepted", C.c_void_p), ("n_accepted", C.c_int64),
+                ("kernel_ms", C.c_float), ("kernel_samples", C.c_int32)]
+
+
+class ChainBatchF32(ChainBatchF64):
+    pass
+
+
 def lib_path(name="libmhlik.so"):
     return os.path.join(_HERE, "lib", name)
 
@@ -92,6 +102,14 @@ _SIGS = [
     ("mhlik_mp_reset", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("mhlik_mp_loglik", C.c_int, [_P, C.POINTER(MpState), _P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mhlik_mp_bound", C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("mhlik_chain_begin_f64", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
+    ("mhlik_chain_begin_f32", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_float)]),
+    ("mhlik_chain_resume_f64", C.c_int, [_P, _P, C.c_double, C.c_double]),
+    ("mhlik_chain_resume_f32", C.c_int, [_P, _P, C.c_float, C.c_double]),
+    ("mhlik_chain_run_f64", C.c_int, [_P, C.POINTER(ChainBatchF64)]),
+    ("mhlik_chain_run_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
+    ("mhlik_chain_state_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    ("mhlik_chain_state_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     ("mhlik_comm_make_id", C.c_int, [_P]),
     ("mhlik_comm_init", C.c_int, [_P, _P]),
     ("mhlik_last_segment_sums", C.c_int, [_P, _P]),

@@ -6,6 +6,7 @@
 #include "mhlik.h"
 
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +19,7 @@
 #include "mhlik_kernels.hpp"
 #include "mhlik_batched.hpp"
 #include "mhlik_mp.hpp"
+#include "mhlik_chain.hpp"
 #include "mhlik_synth.h"
 
 using namespace mhlik;
@@ -32,6 +34,7 @@ thread_local std::string g_create_error;
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 static_assert(sizeof(ncclUniqueId) == MHLIK_COMM_ID_BYTES, "nccl id size");
+static_assert(mhlik::kMaxSegmentsDev == MHLIK_MAX_SEGMENTS, "segment slots of the chain step kernel");
 struct RcclApi {
   void *lib = nullptr;
   int (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -100,6 +103,21 @@ struct Store {
   size_t bytes = 0;
 };
 
+// Device-resident MH chain (mhlik_chain.hpp): state + one batch of buffers.
+struct ChainHost {
+  ChainHdr *hdr = nullptr;
+  void *cur = nullptr, *prop = nullptr;
+  size_t state_bytes = 0;
+  void *inc = nullptr, *logu = nullptr, *samples = nullptr;
+  double *lik = nullptr, *ratio = nullptr;
+  unsigned char *acc = nullptr;
+  int64_t cap_n = 0;
+  size_t batch_elem = 0;
+  double pdf_norm = 0, abs_sigma = 1;
+  int prec = 0;
+  std::vector<hipEvent_t> ev;
+};
+
 } // namespace
 
 struct mhlik_ctx {
@@ -136,6 +154,7 @@ struct mhlik_ctx {
   size_t mp_out_cap = 0;
 
   ncclComm_t comm = nullptr;
+  ChainHost chain;
 
   float last_ms = 0.f;
   int64_t last_bytes = 0;
@@ -167,6 +186,8 @@ int fail(mhlik_ctx *c, int code, const char *fmt, ...)
       return fail((c), e_ == hipErrorOutOfMemory ? MHLIK_ENOMEM : MHLIK_EHIP, "%s failed: %s (%s:%d)", \
                   #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                 \
   } while (0)
+
+void chain_free(ChainHost &h);
 
 struct VariantDef {
   int R, U;
@@ -626,6 +647,7 @@ void mhlik_destroy(mhlik_ctx *c)
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.ok) g_rccl.CommDestroy(c->comm);
+  chain_free(c->chain);
   free_store(c->s64);
   free_store(c->s32);
   if (c->partials) (void)hipFree(c->partials);
@@ -815,3 +837,4 @@ int mhlik_comm_init(mhlik_ctx *c, const uint8_t id[MHLIK_COMM_ID_BYTES])
 
 #include "mhlik_batched_abi.inc"
 #include "mhlik_mp_abi.inc"
+#include "mhlik_chain_abi.inc"

@@ -75,17 +75,30 @@ static void start_chain(mhlik_ctx *lik, mcmc_str mcin, mcmc_int_v v, mcmc_int *l
   loc->cposterior = log_prior_gpu(v.current, mcin) + clhood;
 }
 
+/* n MH iterations from the state in v.current / loc->cposterior; rows: where
+ * the state after each iteration goes (n rows of d, or NULL). */
+static void run_steps(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,
+                      double *rows, int *accepted, out_str *res)
+{
+  const int d = mcin.ddata;
+  if (mh_device_chain_enabled()) {
+    mh_chain_steps_d(lik, r, mcin, sd, v, loc, n, rows, accepted, res, PRIOR_SD);
+    return;
+  }
+  for (long i = 0; i < n; i++) {
+    if (mh_step_d(lik_cb, lik, r, mcin, sd, v, loc, res, PRIOR_SD, 0) && accepted) *accepted += 1;
+    if (rows)
+      for (int k = 0; k < d; k++) rows[i * d + k] = v.current[k];
+  }
+}
+
 /* mcmc_gpu.cu:86-130 */
 void metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata,
                     mcmc_int_v mclocv, mcmc_int *mcloc, int *accepted_samples, out_str *res)
 {
-  const int d = mcin.ddata;
   zero_gpu_times(res);
   MH_SAY("Starting metropolis algorithm. Selected rwsd = %f\n", mct.rwsd);
-  for (int i = 0; i < mcin.Ns; i++) {
-    if (mh_step_d(lik_cb, lik, r, mcin, mct.rwsd, mclocv, mcloc, res, PRIOR_SD, 0)) *accepted_samples += 1;
-    for (int k = 0; k < d; k++) mcdata.samples[(long)i * d + k] = mclocv.current[k];
-  }
+  run_steps(lik, r, mcin, mct.rwsd, mclocv, mcloc, mcin.Ns, mcdata.samples, accepted_samples, res);
   MH_SAY("Metropolis algorithm finished. Accepted Samples = %d\n\n", *accepted_samples);
 }
 
@@ -96,10 +109,7 @@ void burn_in_metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, mcmc_tune
   const int d = mcin.ddata;
   MH_SAY("Starting burn in process. Selected rwsd = %f\n", mct.rwsd);
   start_chain(lik, mcin, mclocv, mcloc, mcdata.burn);
-  for (int i = 1; i < mcin.burnin; i++) {
-    mh_step_d(lik_cb, lik, r, mcin, mct.rwsd, mclocv, mcloc, NULL, PRIOR_SD, 0);
-    for (int k = 0; k < d; k++) mcdata.burn[(long)i * d + k] = mclocv.current[k];
-  }
+  run_steps(lik, r, mcin, mct.rwsd, mclocv, mcloc, mcin.burnin - 1, mcdata.burn + d, NULL, NULL);
   MH_SAY("Burn in process finished.\n\n");
 }
 
@@ -140,18 +150,14 @@ static void short_run_burn_in_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_int_v v, mcmc
                                   const double *initCond)
 {
   start_chain(lik, mcin, v, loc, initCond);
-  for (int i = 1; i < mcin.burnin; i++) mh_step_d(lik_cb, lik, r, mcin, sd, v, loc, NULL, PRIOR_SD, 0);
+  run_steps(lik, r, mcin, sd, v, loc, mcin.burnin - 1, NULL, NULL, NULL);
 }
 
 /* mcmc_gpu.cu:602-637 */
 static void short_run_metropolis_gpu(mhlik_ctx *lik, gsl_rng *r, mcmc_int_v v, mcmc_str mcin, int chain_length,
                                      double sd, mcmc_int *loc, double *samples, int *accepted)
 {
-  const int d = mcin.ddata;
-  for (int i = 0; i < chain_length; i++) {
-    if (mh_step_d(lik_cb, lik, r, mcin, sd, v, loc, NULL, PRIOR_SD, 0)) *accepted += 1;
-    for (int k = 0; k < d; k++) samples[(long)i * d + k] = v.current[k];
-  }
+  run_steps(lik, r, mcin, sd, v, loc, chain_length, samples, accepted, NULL);
 }
 
 static double tuning_round(mhlik_ctx *lik, gsl_rng *r, mcmc_int_v v, mcmc_str mcin, int chain_length, double sd,

@@ -168,6 +168,83 @@ int mh_step_d(mh_lik_d lik, void *env, gsl_rng *r, mcmc_str mcin, double sd, mcm
   return accept;
 }
 
+/* ---- chain on the device (mhlik_chain_*, include/mhlik.h) ----------------
+ * The same iterations as n calls of mh_step_d, with the host drawing the
+ * random numbers of the whole batch first -- in the order the loop above
+ * consumes them: d Gaussians, then one uniform, per iteration -- and the
+ * device doing proposal, likelihood, prior, ratio and accept test back to
+ * back.  MCMC_AMD_HOST_LOOP=1 keeps the per-iteration host loop instead. */
+int mh_device_chain_enabled(void)
+{
+  const char *e = getenv("MCMC_AMD_HOST_LOOP");
+  return (e && e[0] == '1') ? 0 : 1;
+}
+
+#define MH_CHAIN_MAX_BATCH 65536
+
+void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,
+                      double *rows_out, int *accepted, out_str *res, int prior_sd)
+{
+  const int d = mcin.ddata;
+  if (n <= 0) return;
+  const long cap = n < MH_CHAIN_MAX_BATCH ? n : MH_CHAIN_MAX_BATCH;
+  double *inc = (double *)malloc(sizeof(double) * (size_t)cap * d);
+  double *logu = (double *)malloc(sizeof(double) * (size_t)cap);
+  double *lk = (double *)malloc(sizeof(double) * (size_t)cap);
+  double *ratio = (double *)malloc(sizeof(double) * (size_t)cap);
+  uint8_t *acc = (uint8_t *)malloc((size_t)cap);
+  double *rows = rows_out ? NULL : (double *)malloc(sizeof(double) * (size_t)cap * d);
+  if (!inc || !logu || !lk || !ratio || !acc || (!rows_out && !rows)) {
+    fprintf(stderr, "ERROR: chain batch vectors did not allocate.\n");
+    exit(MHLIK_ENOMEM);
+  }
+  MH_CHECK(mhlik_chain_resume_f64(lik, v.current, loc->cposterior, (double)prior_sd), lik);
+  double ms_sum = 0;
+  long ms_n = 0;
+  for (long done = 0; done < n; done += cap) {
+    const long m = n - done < cap ? n - done : cap;
+    for (long i = 0; i < m; i++) {
+      for (int k = 0; k < d; k++) inc[i * d + k] = gsl_ran_gaussian_ziggurat(r, sd);
+      loc->u = gsl_rng_uniform(r);
+      logu[i] = log(loc->u);
+    }
+    mhlik_chain_batch_f64 b;
+    memset(&b, 0, sizeof b);
+    b.n = m;
+    b.increments = inc;
+    b.log_u = logu;
+    b.samples = rows_out ? rows_out + done * d : rows;
+    b.lik = lk;
+    b.ratio = ratio;
+    b.accepted = acc;
+    MH_CHECK(mhlik_chain_run_f64(lik, &b), lik);
+    if (accepted) *accepted += (int)b.n_accepted;
+    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], logu[i], acc[i]);
+    loc->acceptance = ratio[m - 1];
+    if (b.kernel_samples > 0) {
+      ms_sum += (double)b.kernel_ms * b.kernel_samples;
+      ms_n += b.kernel_samples;
+    }
+  }
+  MH_CHECK(mhlik_chain_state_f64(lik, v.current, &loc->cposterior), lik);
+  if (res && ms_n > 0) {
+    float ms = 0;
+    int64_t bytes = 0;
+    mhlik_last_kernel_ms(lik, &ms, &bytes);
+    ms = (float)(ms_sum / ms_n);
+    res->kernelTime = ms;
+    res->kernelBandwidth = (float)((double)bytes / ms / 1e6);
+    res->gpuTime = res->kernelTime;
+    res->gpuBandwidth = res->kernelBandwidth;
+  }
+  free(inc);
+  free(logu);
+  free(lk);
+  free(ratio);
+  free(acc);
+  free(rows);
+}
+
 /* ---- RNG set-up: src/util/alloc_util.c:249-277 ---- */
 void init_rng(gsl_rng **r)
 {

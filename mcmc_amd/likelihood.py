@@ -151,6 +151,48 @@ class Likelihood:
         return s.value, e.value
 
     # -- multi GPU ------------------------------------------------------------
+    # ---- MH chain kept on the device (mhlik_chain_*) ----
+    def chain_begin(self, theta0, prior_sd, dtype=np.float64):
+        """Start a chain at theta0; returns cposterior = prior + L(theta0)."""
+        th = np.ascontiguousarray(theta0, dtype=dtype)
+        if dtype == np.float64:
+            out = C.c_double()
+            self._chk(self._lib.mhlik_chain_begin_f64(self._ctx, _ptr(th), float(prior_sd), C.byref(out)))
+        else:
+            out = C.c_float()
+            self._chk(self._lib.mhlik_chain_begin_f32(self._ctx, _ptr(th), float(prior_sd), C.byref(out)))
+        return out.value
+
+    def chain_resume(self, current, cposterior, prior_sd, dtype=np.float64):
+        cur = np.ascontiguousarray(current, dtype=dtype)
+        fn = self._lib.mhlik_chain_resume_f64 if dtype == np.float64 else self._lib.mhlik_chain_resume_f32
+        self._chk(fn(self._ctx, _ptr(cur), float(cposterior), float(prior_sd)))
+
+    def chain_run(self, increments, log_u, dtype=np.float64):
+        """Run len(log_u) iterations; returns dict(samples, lik, ratio, accepted, n_accepted, kernel_ms)."""
+        inc = np.ascontiguousarray(increments, dtype=dtype)
+        lu = np.ascontiguousarray(log_u, dtype=dtype)
+        n, d = inc.shape
+        samples = np.empty((n, d), dtype=dtype)
+        lik, ratio, acc = np.empty(n), np.empty(n), np.empty(n, dtype=np.uint8)
+        B = L.ChainBatchF64 if dtype == np.float64 else L.ChainBatchF32
+        b = B(n=n, increments=_ptr(inc).value, log_u=_ptr(lu).value, samples=_ptr(samples).value,
+              lik=_ptr(lik).value, ratio=_ptr(ratio).value, accepted=_ptr(acc).value)
+        fn = self._lib.mhlik_chain_run_f64 if dtype == np.float64 else self._lib.mhlik_chain_run_f32
+        self._chk(fn(self._ctx, C.byref(b)))
+        return dict(samples=samples, lik=lik, ratio=ratio, accepted=acc, n_accepted=b.n_accepted,
+                    kernel_ms=b.kernel_ms, kernel_samples=b.kernel_samples)
+
+    def chain_state(self, dtype=np.float64):
+        cur = np.empty(self.n_cols, dtype=dtype)
+        if dtype == np.float64:
+            cp = C.c_double()
+            self._chk(self._lib.mhlik_chain_state_f64(self._ctx, _ptr(cur), C.byref(cp)))
+        else:
+            cp = C.c_float()
+            self._chk(self._lib.mhlik_chain_state_f32(self._ctx, _ptr(cur), C.byref(cp)))
+        return cur, cp.value
+
     @staticmethod
     def make_comm_id():
         lib = L.load_mhlik()

@@ -1,0 +1,128 @@
+"""The MH chain kept on the device (mhlik_chain_*)
+against the per-iteration host loop and the CPU oracle.  The device runs the
+same iterations from the same host-drawn random numbers, so proposals, samples
+and the accept/reject sequence must be identical; the likelihood bits are the
+same kernel's; only the prior (device exp/log vs glibc) may differ in the
+last place."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _both_modes(monkeypatch, fn):
+    monkeypatch.setenv("MCMC_AMD_HOST_LOOP", "1")
+    host = fn()
+    monkeypatch.delenv("MCMC_AMD_HOST_LOOP")
+    dev = fn()
+    return host, dev
+
+
+@pytest.mark.parametrize("N,d,segments", [(10000, 3, 0), (30000, 16, 0), (4000, 64, 32), (2500, 300, 0)])
+def test_device_chain_equals_host_loop(monkeypatch, N, d, segments):
+    from mcmc_amd import Likelihood, samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(777, N, d)
+    Ns, burnin, rwsd = 200, 40, 2.38 / np.sqrt(d) * 0.05
+
+    def run():
+        with Likelihood(N, d, segments=segments, timing=True) as lk:
+            lk.upload(X)
+            with S.attached(lk):
+                return S.gpu_sampler(None, 5, Ns, burnin, rwsd, n_rows=N, n_cols=d)
+
+    host, dev = _both_modes(monkeypatch, run)
+    assert np.array_equal(host["trace"]["accept"], dev["trace"]["accept"])
+    assert np.array_equal(host["samples"], dev["samples"])
+    assert np.array_equal(host["burn"], dev["burn"])
+    assert np.array_equal(host["trace"]["lik"], dev["trace"]["lik"]), "same kernel, same theta bits -> same L bits"
+    assert np.array_equal(host["trace"]["logu"], dev["trace"]["logu"])
+    assert np.allclose(host["trace"]["ratio"], dev["trace"]["ratio"], rtol=0, atol=1e-9)
+    assert host["acceptance"] == dev["acceptance"]
+    assert dev["res"].kernelTime > 0
+
+
+def test_device_chain_equals_oracle_and_tuner(monkeypatch):
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 20000, 8
+    X = synthetic_host(4242, N, d)
+    ref = O.cpu_sampler(X, 3, 500, 100, 0.02)
+    got = S.gpu_sampler(X, 3, 500, 100, 0.02)
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"])
+    assert np.array_equal(ref["samples"], got["samples"])
+    rel = np.abs(ref["trace"]["lik"] - got["trace"]["lik"]) / np.abs(ref["trace"]["lik"])
+    assert rel.max() <= 1e-10
+    host, dev = _both_modes(monkeypatch, lambda: S.tune_target_a_gpu_v2(X, 7, 50, 2.38 / np.sqrt(d), 0.25, 3))
+    assert host == dev
+
+
+def test_chain_abi_begin_run_state():
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, sd = 12000, 5, 10.0
+    X = synthetic_host(99, N, d)
+    rng = np.random.default_rng(0)
+    th0 = rng.normal(0, 0.1, d)
+    n = 64
+    inc = rng.normal(0, 0.02, (n, d))
+    logu = np.log(rng.uniform(size=n))
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        cp = lk.chain_begin(th0, sd)
+        L0 = lk.loglik(th0)
+        prior0 = sum(np.log(np.exp(-(x / sd) ** 2 / 2) / (np.sqrt(2 * np.pi) * sd)) for x in th0)
+        assert abs(cp - (prior0 + L0)) <= 1e-12 * abs(cp)
+        out = lk.chain_run(inc, logu)
+        # replay on the host with the library's own single-theta likelihood
+        cur, cpost = th0.copy(), cp
+        for i in range(n):
+            prop = cur + inc[i]
+            Lp = lk.loglik(prop)
+            assert Lp == out["lik"][i]
+            pp = sum(np.log(np.exp(-(x / sd) ** 2 / 2) / (np.sqrt(2 * np.pi) * sd)) for x in prop) + Lp
+            a = logu[i] <= pp - cpost
+            assert bool(out["accepted"][i]) == bool(a)
+            if a:
+                cur, cpost = prop, pp
+            assert np.array_equal(out["samples"][i], cur)
+        cur_dev, cp_dev = lk.chain_state()
+        assert np.array_equal(cur_dev, cur)
+        assert abs(cp_dev - cpost) <= 1e-12 * abs(cpost)
+        assert out["n_accepted"] == int(out["accepted"].sum())
+        # a second batch continues from the device-side state; resume restarts from a host-side one
+        out2 = lk.chain_run(inc[:8], logu[:8])
+        lk.chain_resume(cur, cp_dev, sd)
+        out3 = lk.chain_run(inc[:8], logu[:8])
+        assert np.array_equal(out2["samples"], out3["samples"])
+
+
+def test_chain_over_forced_rccl_is_bitwise_equal(monkeypatch):
+    """One-rank communicator (MHLIK_FORCE_COMM=1): segment kernel -> ncclAllReduce
+    on the stream -> step kernel, the path N ranks take."""
+    from mcmc_amd import Likelihood
+
+    N, d = 100_000, 16
+    rng = np.random.default_rng(2)
+    inc = rng.normal(0, 0.01, (50, d))
+    logu = np.log(rng.uniform(size=50))
+
+    def run(force):
+        with Likelihood(N, d, device=0) as lk:
+            lk.fill_synthetic(31)
+            if force:
+                lk.comm_init(Likelihood.make_comm_id())
+            cp = lk.chain_begin(np.zeros(d), 10.0)
+            return cp, lk.chain_run(inc, logu)
+
+    cp0, plain = run(False)
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    cp1, forced = run(True)
+    assert cp0 == cp1
+    for k in ("samples", "lik", "ratio", "accepted"):
+        assert np.array_equal(plain[k], forced[k]), k
