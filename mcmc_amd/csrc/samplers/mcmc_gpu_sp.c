@@ -21,6 +21,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 static const int PRIOR_SD = 10;
@@ -79,6 +80,87 @@ static int step_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, mcmc_int_
   return accept;
 }
 
+/* n iterations of step_f with the chain kept on the device (mhlik_chain_run_f32):
+ * the host draws the batch's numbers in step_f's order -- d float-rounded
+ * Gaussians, then one uniform rounded to float -- and the device runs the
+ * float chain: float proposal, float prior accumulator += double log(pdf),
+ * float posterior and ratio, logf(uf) <= ratio. */
+static void chain_steps_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, mcmc_int_v v, mcmc_int *loc, long n,
+                          float *rows_out, int *accepted, out_str *res)
+{
+  const int d = mcin.ddata;
+  if (n <= 0) return;
+  const long cap = n < 65536 ? n : 65536;
+  float *inc = (float *)malloc(sizeof(float) * (size_t)cap * d);
+  float *logu = (float *)malloc(sizeof(float) * (size_t)cap);
+  double *lk = (double *)malloc(sizeof(double) * (size_t)cap);
+  double *ratio = (double *)malloc(sizeof(double) * (size_t)cap);
+  uint8_t *acc = (uint8_t *)malloc((size_t)cap);
+  if (!inc || !logu || !lk || !ratio || !acc) {
+    fprintf(stderr, "ERROR: chain batch vectors did not allocate.\n");
+    exit(MHLIK_ENOMEM);
+  }
+  MH_CHECK(mhlik_chain_resume_f32(lik, v.currentf, loc->cposteriorf, (double)PRIOR_SD), lik);
+  double ms_sum = 0;
+  long ms_n = 0;
+  for (long done = 0; done < n; done += cap) {
+    const long m = n - done < cap ? n - done : cap;
+    for (long i = 0; i < m; i++) {
+      for (int k = 0; k < d; k++) inc[i * d + k] = (float)gsl_ran_gaussian_ziggurat(r, (double)sd);
+      loc->uf = gsl_rng_uniform(r);
+      logu[i] = logf(loc->uf);
+    }
+    mhlik_chain_batch_f32 b;
+    memset(&b, 0, sizeof b);
+    b.n = m;
+    b.increments = inc;
+    b.log_u = logu;
+    b.samples = rows_out ? rows_out + done * d : NULL;
+    b.lik = lk;
+    b.ratio = ratio;
+    b.accepted = acc;
+    MH_CHECK(mhlik_chain_run_f32(lik, &b), lik);
+    if (accepted) *accepted += (int)b.n_accepted;
+    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], logu[i], acc[i]);
+    loc->acceptancef = (float)ratio[m - 1];
+    if (b.kernel_samples > 0) {
+      ms_sum += (double)b.kernel_ms * b.kernel_samples;
+      ms_n += b.kernel_samples;
+    }
+  }
+  MH_CHECK(mhlik_chain_state_f32(lik, v.currentf, &loc->cposteriorf), lik);
+  if (res && ms_n > 0) {
+    float ms = 0;
+    int64_t bytes = 0;
+    mhlik_last_kernel_ms(lik, &ms, &bytes);
+    ms = (float)(ms_sum / ms_n);
+    res->kernelTime = ms;
+    res->kernelBandwidth = (float)((double)bytes / ms / 1e6);
+    res->gpuTime = res->kernelTime;
+    res->gpuBandwidth = res->kernelBandwidth;
+  }
+  free(inc);
+  free(logu);
+  free(lk);
+  free(ratio);
+  free(acc);
+}
+
+static void run_steps_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, mcmc_int_v v, mcmc_int *loc, long n,
+                        float *rows, int *accepted, out_str *res)
+{
+  const int d = mcin.ddata;
+  if (mh_device_chain_enabled()) {
+    chain_steps_f(lik, r, mcin, sd, v, loc, n, rows, accepted, res);
+    return;
+  }
+  for (long i = 0; i < n; i++) {
+    if (step_f(lik, r, mcin, sd, v, loc, res) && accepted) *accepted += 1;
+    if (rows)
+      for (int k = 0; k < d; k++) rows[i * d + k] = v.currentf[k];
+  }
+}
+
 static void start_chain_f(mhlik_ctx *lik, mcmc_str mcin, mcmc_int_v v, mcmc_int *loc, const float *theta0)
 {
   for (int k = 0; k < mcin.ddata; k++) v.currentf[k] = theta0[k];
@@ -104,10 +186,7 @@ void sp_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcm
   if (mcin.burnin != 0) { /* burn_in_metropolis_sp, :132-177 */
     MH_SAY("Starting burn in process. Selected rwsdf = %f\n", mct.rwsdf);
     start_chain_f(lik, mcin, v, &loc, mcdata.burnf);
-    for (int i = 1; i < mcin.burnin; i++) {
-      step_f(lik, r, mcin, mct.rwsdf, v, &loc, NULL);
-      for (int k = 0; k < d; k++) mcdata.burnf[(long)i * d + k] = v.currentf[k];
-    }
+    run_steps_f(lik, r, mcin, mct.rwsdf, v, &loc, mcin.burnin - 1, mcdata.burnf + d, NULL, NULL);
     MH_SAY("Burn in process finished.\n\n");
   }
   clock_t burn = clock() - t0;
@@ -119,10 +198,7 @@ void sp_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcm
     res->kernelTime = res->kernelBandwidth = 0;
     res->gpuTime = res->gpuBandwidth = 0;
     MH_SAY("Starting metropolis algorithm. Selected rwsdf = %f\n", mct.rwsdf);
-    for (int i = 0; i < mcin.Ns; i++) {
-      if (step_f(lik, r, mcin, mct.rwsdf, v, &loc, res)) accepted += 1;
-      for (int k = 0; k < d; k++) mcdata.samplesf[(long)i * d + k] = v.currentf[k];
-    }
+    run_steps_f(lik, r, mcin, mct.rwsdf, v, &loc, mcin.Ns, mcdata.samplesf, &accepted, res);
     MH_SAY("Metropolis algorithm finished. Accepted Samples = %d\n\n", accepted);
   }
   clock_t run = clock() - t0;
@@ -139,14 +215,10 @@ void sp_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcm
 static float tuning_round_f(mhlik_ctx *lik, gsl_rng *r, mcmc_int_v v, mcmc_str mcin, int chain_length, float sd,
                             mcmc_int *loc, float *samples, const float *initCond)
 {
-  const int d = mcin.ddata;
   int accepted = 0;
   start_chain_f(lik, mcin, v, loc, initCond);
-  for (int i = 1; i < mcin.burnin; i++) step_f(lik, r, mcin, sd, v, loc, NULL);
-  for (int i = 0; i < chain_length; i++) {
-    if (step_f(lik, r, mcin, sd, v, loc, NULL)) accepted += 1;
-    for (int k = 0; k < d; k++) samples[(long)i * d + k] = v.currentf[k];
-  }
+  run_steps_f(lik, r, mcin, sd, v, loc, mcin.burnin - 1, NULL, NULL, NULL);
+  run_steps_f(lik, r, mcin, sd, v, loc, chain_length, samples, &accepted, NULL);
   return accepted / (float)chain_length;
 }
 

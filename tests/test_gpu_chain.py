@@ -126,3 +126,23 @@ def test_chain_over_forced_rccl_is_bitwise_equal(monkeypatch):
     assert cp0 == cp1
     for k in ("samples", "lik", "ratio", "accepted"):
         assert np.array_equal(plain[k], forced[k]), k
+
+
+@pytest.mark.parametrize("N,d", [(10000, 3), (40000, 16)])
+def test_sp_device_chain_equals_host_loop(monkeypatch, N, d):
+    """Float chain (sp_sampler): float proposals, float prior accumulator fed
+    double log(pdf) terms, float posterior / ratio, logf(uf) <= ratio."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    Xf = np.asfortranarray(synthetic_host(555, N, d).astype(np.float32))
+    host, dev = _both_modes(monkeypatch, lambda: S.sp_sampler(Xf, 11, 300, 50, 2.38 / np.sqrt(d) * 0.05))
+    assert np.array_equal(host["trace"]["lik"], dev["trace"]["lik"])
+    assert np.array_equal(host["trace"]["logu"], dev["trace"]["logu"])
+    # the float ratio is quantised at ~1e-3 here; a last-place difference of the
+    # device's double log(pdf) can move it by one float ulp at most
+    assert np.allclose(host["trace"]["ratio"], dev["trace"]["ratio"], rtol=2e-7, atol=0)
+    assert np.array_equal(host["trace"]["accept"], dev["trace"]["accept"])
+    assert np.array_equal(host["samples"], dev["samples"])
+    assert np.array_equal(host["burn"], dev["burn"])
+    assert host["acceptance"] == dev["acceptance"]
