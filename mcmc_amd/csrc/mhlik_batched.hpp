@@ -48,9 +48,11 @@ __device__ __forceinline__ float neg_log1pexp_fast(float x)
 // Workgroup = 256 threads = 4 waves; f32 tile = 1024 rows; wave w owns rows
 // [256w, 256w+256) in two passes of 128 rows (32 A-rows x 4 row sets).
 // NB = number of 32-chain blocks (1: K <= 32, 2: K <= 64).  KU = k-steps
-// (pairs of columns) whose loads are in flight together.
+// (pairs of columns) whose loads are in flight together.  EXP != 0 builds the
+// ablations tools/batched_lab.hip times (bit 0: plain sum instead of the
+// transcendental epilogue, bit 1: no global loads inside the k-loop).
 // LDS: thetaL[(j*32 + c)*2 + n] = Theta[j][n*32 + c]  (float2 per (j, c)).
-template <int NB, int KU>
+template <int NB, int KU, int EXP = 0>
 __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float *__restrict__ X, TileGeom g,
                                                                     const int32_t *__restrict__ tile_valid,
                                                                     const float *__restrict__ theta_dev, int d_pad,
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
     for (int bt = 0; bt < nfull; bt++, j0 += 2 * KU) {
 #pragma unroll
       for (int u = 0; u < KU; u++) a[u] = an[u];
-      if (bt + 1 < nfull) {
+      if (!(EXP & 2) && bt + 1 < nfull) {
 #pragma unroll
         for (int u = 0; u < KU; u++)
           an[u] = load16<float, true>(rbase + (int64_t)(j0 + 2 * KU + 2 * u + kk) * g.col_stride);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 #pragma unroll
         for (int n = 0; n < NB; n++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) sum[n] += neg_log1pexp_fast(acc[m][n][r]);
+          for (int r = 0; r < 16; r++) sum[n] += (EXP & 1) ? acc[m][n][r] : neg_log1pexp_fast(acc[m][n][r]);
     } else {
 #pragma unroll
       for (int m = 0; m < 4; m++)
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 // rows (16 A-rows x 4 row sets: two double2 loads per lane per k-step).
 // NB = number of 16-chain blocks (1..4).  One k-step = 4 columns.
 // LDS: thetaL[(j*16 + c)*4 + n] = Theta[j][n*16 + c]  (4 doubles per (j, c)).
-template <int NB, int KU>
+template <int NB, int KU, int EXP = 0>
 __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double *__restrict__ X, TileGeom g,
                                                                     const int32_t *__restrict__ tile_valid,
                                                                     const double *__restrict__ theta_dev, int d_pad,
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         a0[u] = n0[u];
         a1[u] = n1[u];
       }
-      if (bt + 1 < nfull) {
+      if (!(EXP & 2) && bt + 1 < nfull) {
 #pragma unroll
         for (int u = 0; u < KU; u++) {
           const double *col = rbase + (int64_t)(j0 + 4 * KU + 4 * u + kk) * g.col_stride;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         const bool ok = full || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
 #pragma unroll
         for (int n = 0; n < NB; n++)
-          if (ok) sum[n] += neg_log1pexp(acc[m][n][r]);
+          if (ok) sum[n] += (EXP & 1) ? acc[m][n][r] : neg_log1pexp(acc[m][n][r]);
       }
   }
 
