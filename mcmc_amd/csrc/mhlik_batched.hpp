@@ -21,12 +21,15 @@
 //   f64: v_mfma_f64_16x16x4_f64   A[i=l&15][k=l>>4], B[k=l>>4][n=l&15],
 //        C: col = l&15, row = (l>>4) + 4*r, r in [0,4)
 //
+// (f64: mhlik_neg_softplus, the same function in half the FP64 instructions of
+// exp followed by log -- the epilogue shares the FP64 lanes with the MFMA.)
 // Epilogue: -log(1+exp(.)) on every accumulator element, per-chain sum over
 // the tile's rows (registers -> LDS -> fixed order), one partial per (chain,
 // tile): partials[chain*pstride + tile], reduced by segment_sum_kernel.
 #pragma once
 
 #include "mhlik_kernels.hpp"
+#include "mhlik_softplus.h"
 
 namespace mhlik {
 
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         const bool ok = full || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
 #pragma unroll
         for (int n = 0; n < NB; n++)
-          if (ok) sum[n] += (EXP & 1) ? acc[m][n][r] : neg_log1pexp(acc[m][n][r]);
+          if (ok) sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
       }
   }
 

@@ -81,3 +81,15 @@ def test_multichain_sampler_reproduces_single_chains():
         assert np.array_equal(out["samples"][k], ref["samples"]), k
         assert np.array_equal(out["burn"][k], ref["burn"]), k
         assert out["accepted"][k] == int(ref["trace"]["accept"][39:].sum())
+
+
+def test_fast_softplus_on_device():
+    """mhlik_neg_softplus as compiled for gfx950 (the K-chain double kernel's
+    epilogue) against a long double evaluation: tools/check_softplus."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_softplus")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -117,7 +117,8 @@ int main(int argc, char **argv)
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
       printf("f64 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
-    RUN64(0, "current")
+    RUN64(0, "current (fast softplus)")
+    RUN64(4, "ocml exp + log epilogue")
     RUN64(1, "no transcendental epilogue")
     RUN64(2, "no global loads in k-loop")
     RUN64(3, "neither")
