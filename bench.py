@@ -133,7 +133,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "Bayesian logistic regression MH, N=%d d=%d DP (BASELINE configs[2])" % (N, d),
+        "config": {"workload": "Bayesian logistic regression MH, N=%d d=%d DP (%s)" % (N, d, workload_name(N, d)),
                    "rows": N, "cols": d, "rows_per_gpu": info["local_rows"],
                    "parallelism": "rows sharded over %d GPU(s), per-iteration RCCL all-reduce" % world
                    if world > 1 else "single GPU"},
@@ -156,6 +156,12 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def workload_name(N, d):
+    """Which BASELINE.json configuration these sizes are."""
+    return {(1_000_000, 16): "BASELINE configs[1]", (10_000_000, 64): "BASELINE configs[2], the metric's N=10M d=64",
+            (100_000_000, 64): "BASELINE configs[3]"}.get((N, d), "custom size")
 
 
 def pmc_traffic(N, d, local_rows):
@@ -211,6 +217,7 @@ def cpu_baseline(a, np, N, d, rwsd, lk, S):
     from mcmc_amd.likelihood import synthetic_host
 
     X = synthetic_host(a.data_seed, N, d)
+    upload = host_upload_rate(X, N, d)
     iters, burn = a.cpu_iters, 2
     t0 = time.perf_counter()
     r = O.cpu_sampler(X, a.seed, iters, burn, rwsd)
@@ -235,7 +242,20 @@ def cpu_baseline(a, np, N, d, rwsd, lk, S):
                        "samples_equal": bool(np.array_equal(r["samples"], g["samples"])),
                        "max_rel_loglik_diff": float(rel.max()) if len(rel) else None,
                        "min_decision_margin": float(np.abs(ct["logu"] - ct["ratio"]).min()) if len(rel) else None},
-            "all_cores": {"it_per_s_likelihood_only": 1.0 / mt, "cores": ncores}}
+            "all_cores": {"it_per_s_likelihood_only": 1.0 / mt, "cores": ncores},
+            "host_upload": upload}
+
+
+def host_upload_rate(X, N, d):
+    """One-time cost outside the per-iteration path: mhlik_upload_f64 of the
+    host column-major matrix (pageable memory -> tiled layout in HBM)."""
+    from mcmc_amd import Likelihood, F64
+
+    with Likelihood(N, d, precision=F64) as up:
+        t0 = time.perf_counter()
+        up.upload(X)
+        el = time.perf_counter() - t0
+    return {"seconds": el, "GBps": N * d * 8 / el / 1e9, "bytes": N * d * 8}
 
 
 if __name__ == "__main__":
