@@ -163,6 +163,40 @@ int mhlik_mp_loglik(mhlik_ctx *ctx, const mhlik_mp_state *st, const double *thet
  * extreme of epsilon_i = sigma_D - sigma_S over all rows. */
 int mhlik_mp_bound(mhlik_ctx *ctx, const double *theta, double *sum_lb, double *epsilon);
 
+/* ---- mixed precision, K lock-step chains (BASELINE.json config 5) -------
+ *
+ * No counterpart in the reference (one chain per mp_likelihood call,
+ * src/mcmc_mp/mcmc_mp.cu:475-552).  Chain k is exactly the single-chain
+ * definition above with its own indicators, its own re-examination phase
+ * resamp_choose[k] and its own per-block uniforms u_seed[k]; all chains share
+ * block_rows, blocks, resamp_factor, the call counter and the bound.  The
+ * float dots of ALL rows and chains (the reference's cublasSgemv over the
+ * whole matrix, :515) run as one X.Theta pass on the matrix cores; double
+ * arithmetic touches only the (block, chain) pairs that are bright or
+ * re-examined in this call.  Needs segments=1, world=1, both matrices. */
+typedef struct mhlik_mp_batch {
+  int32_t block_rows;           /* mp_str.dataBlockSz */
+  int32_t blocks;               /* mp_str.dataBlocks */
+  int32_t resamp_factor;        /* mp_str.ResampFactor */
+  int32_t K;                    /* chains, 1..MHLIK_MAX_BATCH */
+  const int32_t *resamp_choose; /* host [K]: gsl_rng_uniform_int(r_k, ResampFactor), mcmc_mp.cu:504 */
+  const uint64_t *u_seed;       /* host [K]: seed of chain k's per-block uniforms */
+  uint64_t u_call;              /* call counter */
+  double bound_eps;             /* lhoodBound */
+} mhlik_mp_batch;
+
+/* (Re)initialise K sets of indicators: every block bright for every chain. */
+int mhlik_mp_reset_batched(mhlik_ctx *ctx, int32_t block_rows, int32_t blocks, int32_t K);
+
+/* One mixed-precision evaluation of K proposals.  Theta is host row-major
+ * [K][n_cols]; out[k] = red_d + red_f of chain k; bright_blocks / dark_blocks
+ * (host [K], may be NULL) are the counts after resampling. */
+int mhlik_mp_loglik_batched(mhlik_ctx *ctx, const mhlik_mp_batch *st, const double *Theta, double *out,
+                            int32_t *bright_blocks, int32_t *dark_blocks);
+
+/* Copy the indicators to the host as [K][blocks] (tests / diagnostics). */
+int mhlik_mp_indicators_batched(mhlik_ctx *ctx, int8_t *z);
+
 /* ---- MH chain kept on the device -----------
  *
  * Replaces the per-iteration host round trip of the reference's loop

@@ -64,6 +64,19 @@ class MpState(C.Structure):
     ]
 
 
+class MpBatch(C.Structure):
+    _fields_ = [
+        ("block_rows", C.c_int32),
+        ("blocks", C.c_int32),
+        ("resamp_factor", C.c_int32),
+        ("K", C.c_int32),
+        ("resamp_choose", C.c_void_p),
+        ("u_seed", C.c_void_p),
+        ("u_call", C.c_uint64),
+        ("bound_eps", C.c_double),
+    ]
+
+
 class ChainBatchF64(C.Structure):
     _fields_ = [("n", C.c_int64), ("increments", C.c_void_p), ("log_u", C.c_void_p), ("samples", C.c_void_p),
                 ("lik", C.c_void_p), ("ratio", C.c_void_p), ("accepted", C.c_void_p), ("n_accepted", C.c_int64),
@@ -102,6 +115,9 @@ _SIGS = [
     ("mhlik_mp_reset", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("mhlik_mp_loglik", C.c_int, [_P, C.POINTER(MpState), _P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mhlik_mp_bound", C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("mhlik_mp_reset_batched", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    ("mhlik_mp_loglik_batched", C.c_int, [_P, C.POINTER(MpBatch), _P, _P, _P, _P]),
+    ("mhlik_mp_indicators_batched", C.c_int, [_P, _P]),
     ("mhlik_chain_begin_f64", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
     ("mhlik_chain_begin_f32", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_float)]),
     ("mhlik_chain_resume_f64", C.c_int, [_P, _P, C.c_double, C.c_double]),

@@ -19,6 +19,7 @@
 #include "mhlik_kernels.hpp"
 #include "mhlik_batched.hpp"
 #include "mhlik_mp.hpp"
+#include "mhlik_mp_batched.hpp"
 #include "mhlik_chain.hpp"
 #include "mhlik_synth.h"
 
@@ -152,6 +153,15 @@ struct mhlik_ctx {
   int32_t mp_blocks = 0, mp_block_rows = 0;
   double *mp_out = nullptr; // device scratch
   size_t mp_out_cap = 0;
+  // mixed precision, K chains (mhlik_mp_batched.hpp)
+  int8_t *mpb_z = nullptr;      // [blocks][64]
+  int32_t mpb_blocks = 0, mpb_block_rows = 0, mpb_K = 0;
+  double *mpb_acc = nullptr;    // [kMpbFixWaves][64] bright sums
+  int32_t *mpb_cnt = nullptr;   // [kMpbFixWaves][64] bright counts
+  double *mpb_theta = nullptr;  // [64][d] row-major
+  float *mpb_thetaf = nullptr;
+  void *mpb_args = nullptr;     // device MpbChainArgs
+  double *mpb_res = nullptr, *mpb_res_dev = nullptr; // pinned host [64][4] and its device view
 
   ncclComm_t comm = nullptr;
   ChainHost chain;
@@ -188,6 +198,7 @@ int fail(mhlik_ctx *c, int code, const char *fmt, ...)
   } while (0)
 
 void chain_free(ChainHost &h);
+void mpb_free(mhlik_ctx *c);
 
 struct VariantDef {
   int R, U;
@@ -659,6 +670,7 @@ void mhlik_destroy(mhlik_ctx *c)
   if (c->rowdots) (void)hipFree(c->rowdots);
   if (c->mp_z) (void)hipFree(c->mp_z);
   if (c->mp_out) (void)hipFree(c->mp_out);
+  mpb_free(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -837,4 +849,5 @@ int mhlik_comm_init(mhlik_ctx *c, const uint8_t id[MHLIK_COMM_ID_BYTES])
 
 #include "mhlik_batched_abi.inc"
 #include "mhlik_mp_abi.inc"
+#include "mhlik_mp_batched_abi.inc"
 #include "mhlik_chain_abi.inc"

@@ -47,6 +47,57 @@ __device__ __forceinline__ float neg_log1pexp_fast(float x)
   return -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);
 }
 
+// One 128-row pass of a wave: acc[m][n] = rows {row0 + 4i + m} x chains of
+// N-block n, accumulated over all d columns.  rbase = tile + row0 + 4*arow.
+template <int NB, int KU, int EXP>
+__device__ __forceinline__ void batched_f32_pass(const float *__restrict__ rbase, int64_t col_stride, int d,
+                                                 const float *thetaL, int arow, int kk, f32x16 (&acc)[4][NB])
+{
+  typedef Vec16<float>::type V4;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NB; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+  // software pipeline: the loads of batch b+1 are issued before the MFMAs of batch b
+  int j0 = 0;
+  const int nfull = d / (2 * KU);
+  V4 a[KU], an[KU];
+  if (nfull > 0) {
+#pragma unroll
+    for (int u = 0; u < KU; u++) an[u] = load16<float, true>(rbase + (int64_t)(2 * u + kk) * col_stride);
+  }
+  for (int bt = 0; bt < nfull; bt++, j0 += 2 * KU) {
+#pragma unroll
+    for (int u = 0; u < KU; u++) a[u] = an[u];
+    if (!(EXP & 2) && bt + 1 < nfull) {
+#pragma unroll
+      for (int u = 0; u < KU; u++)
+        an[u] = load16<float, true>(rbase + (int64_t)(j0 + 2 * KU + 2 * u + kk) * col_stride);
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + ((j0 + 2 * u + kk) * 32 + arow) * 2);
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  for (; j0 < d; j0 += 2) { // leftover k-steps; a column >= d contributes zeros
+    const int col = j0 + kk;
+    V4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (col < d) a1 = load16<float, true>(rbase + (int64_t)col * col_stride);
+    const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + (col * 32 + arow) * 2);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b[n], acc[m][n], 0, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------- f32
 // Workgroup = 256 threads = 4 waves; f32 tile = 1024 rows; wave w owns rows
 // [256w, 256w+256) in two passes of 128 rows (32 A-rows x 4 row sets).
@@ -89,48 +140,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
     const int row0 = wave * 256 + pass * 128; // first tile row of this pass
     const float *rbase = tbase + row0 + 4 * arow;
     f32x16 acc[4][NB];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int n = 0; n < NB; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-
-    // software pipeline: the loads of batch b+1 are issued before the MFMAs of batch b
-    int j0 = 0;
-    const int nfull = d / (2 * KU);
-    V4 a[KU], an[KU];
-    if (nfull > 0) {
-#pragma unroll
-      for (int u = 0; u < KU; u++) an[u] = load16<float, true>(rbase + (int64_t)(2 * u + kk) * g.col_stride);
-    }
-    for (int bt = 0; bt < nfull; bt++, j0 += 2 * KU) {
-#pragma unroll
-      for (int u = 0; u < KU; u++) a[u] = an[u];
-      if (!(EXP & 2) && bt + 1 < nfull) {
-#pragma unroll
-        for (int u = 0; u < KU; u++)
-          an[u] = load16<float, true>(rbase + (int64_t)(j0 + 2 * KU + 2 * u + kk) * g.col_stride);
-      }
-#pragma unroll
-      for (int u = 0; u < KU; u++) {
-        const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + ((j0 + 2 * u + kk) * 32 + arow) * 2);
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-          for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[n], acc[m][n], 0, 0, 0);
-      }
-    }
-    for (; j0 < d; j0 += 2) { // leftover k-steps; a column >= d contributes zeros
-      const int col = j0 + kk;
-      V4 a = {0.f, 0.f, 0.f, 0.f};
-      if (col < d) a = load16<float, true>(rbase + (int64_t)col * g.col_stride);
-      const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + (col * 32 + arow) * 2);
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
+    batched_f32_pass<NB, KU, EXP>(rbase, g.col_stride, d, thetaL, arow, kk, acc);
 
     // epilogue: accumulator (m, n, r) of lane l is tile row  row0 + 4*i + m  with
     // i = (r&3) + 8*(r>>2) + 4*(l>>5), chain n*32 + (l&31)

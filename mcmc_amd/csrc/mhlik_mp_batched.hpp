@@ -1,0 +1,337 @@
+// mhlik_mp_batched.hpp -- mixed precision for K lock-step chains (BASELINE.json
+// config 5: "mcmc_mp with 64 batched chains, X.Theta on MFMA").
+//
+// Per chain the definition is the one of mhlik_mp.hpp / oracle/mp_path.c
+// (src/mcmc_mp/mcmc_mp.cu:28-200,475-552): every chain k has its own bright /
+// dark indicators z[block][k], its own re-examination phase resamp_choose[k]
+// and its own per-block uniforms (seed[k]).  The work is split by what it
+// needs, not by data block:
+//
+//   mpb_dark_kernel  the float pass over ALL rows for ALL chains -- the
+//                    reference's cublasSgemv over the whole matrix
+//                    (mcmc_mp.cu:515) -- as X.Theta on v_mfma_f32_32x32x2_f32
+//                    (the pass of mhlik_batched.hpp, bit-for-bit the k-ordered
+//                    fmaf chain of the single-chain kernel).  Epilogue per
+//                    (row, chain): B = sigma_S - eps, log B on the hardware
+//                    exp2/rcp/log2 units, summed per chain over the rows whose
+//                    data block is DARK for that chain.  MFMA-bound.
+//   mpb_fix_kernel   the double-precision correction, only for the (block,
+//                    chain) pairs that are bright or re-examined this call:
+//                    one wave per data block, one row per lane; the block's
+//                    double and float rows are loaded ONCE and dotted against
+//                    the theta of every chain that needs the block (<= 4 at a
+//                    time, theta through scalar loads).  Row terms are exactly
+//                    the single-chain kernel's (same madd / fmaf chains, the
+//                    shared deterministic float sigmoid); z is resampled with
+//                    P(bright) = 1 - exp(sum(log B - log L)).  Lane k of a wave
+//                    keeps chain k's running bright sum and bright count over
+//                    the blocks the wave visits (block b -> wave b mod 2048), so
+//                    there are no atomics and the result does not depend on
+//                    scheduling.
+//   mpb_final_kernel one workgroup per chain adds the tile partials of the dark
+//                    pass and the 2048 per-wave bright sums / counts.
+//
+// Dark rows use fast float math (they are a float sum in the reference too);
+// everything that decides z or enters log(L - B) is the exact per-row
+// arithmetic of the single-chain path, so chain k reproduces mhlik_mp_loglik
+// run with (theta_k, z_k, resamp_choose_k, seed_k) to float-sum tolerance with
+// identical indicators (tests/test_gpu_mp_batched.py).
+#pragma once
+
+#include "mhlik_batched.hpp"
+#include "mhlik_mp.hpp"
+
+namespace mhlik {
+
+constexpr int kMpbFixGroups = 512;                 // workgroups of the fix kernel (fixed: it shapes the sums)
+constexpr int kMpbFixWaves = kMpbFixGroups * 4;    // block b is visited by wave b mod kMpbFixWaves
+constexpr int kMpbGroup = 4;                       // chains dotted against one load of a block's rows
+
+struct MpbParams {
+  int32_t block_rows;   // 64 .. 1024, power of two
+  int32_t block_shift;  // log2(block_rows)
+  int32_t blocks;
+  int32_t resamp_factor;
+  int32_t K;
+  int32_t pad;
+  uint64_t u_call;
+  double eps;
+  int64_t n_rows;
+};
+
+struct MpbChainArgs {
+  int32_t choose[kBatchCols];
+  uint64_t seed[kBatchCols];
+};
+
+// log(sigmoid - eps) with sigmoid = 1/(1+e^x) on v_exp_f32 / v_rcp_f32 / v_log_f32
+__device__ __forceinline__ float mpb_dark_term(float x, float eps)
+{
+  const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+  const float sig = __builtin_amdgcn_rcpf(1.0f + e);
+  return 0.69314718055994531f * __builtin_amdgcn_logf(sig - eps);
+}
+
+// grid = f32 tiles (1024 rows); z: [block][64 chains]; partials[chain*pstride + tile]
+template <int NB, int KU>
+__global__ __launch_bounds__(kBlock, 2) void mpb_dark_kernel(const float *__restrict__ X, TileGeom g,
+                                                             const float *__restrict__ theta_dev, int d_pad,
+                                                             MpbParams p, const int8_t *__restrict__ z,
+                                                             double *__restrict__ partials, int64_t pstride)
+{
+  typedef Vec16<float>::type V4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *thetaL = reinterpret_cast<float *>(smem);
+  double *red = reinterpret_cast<double *>(smem + (size_t)d_pad * kBatchCols * sizeof(float)); // [4 waves][NB][64 lanes]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int d = g.d;
+  for (int i = threadIdx.x * 4; i < d_pad * kBatchCols; i += kBlock * 4)
+    *reinterpret_cast<V4 *>(thetaL + i) = *reinterpret_cast<const V4 *>(theta_dev + i);
+  __syncthreads();
+
+  const int arow = lane & 31, kk = lane >> 5;
+  const float *tbase = X + tile * g.tile_stride;
+  const int64_t all = (int64_t)p.blocks << p.block_shift;
+  const int64_t covered = all < p.n_rows ? all : p.n_rows; // rows that belong to a considered block
+  const float epsf = (float)p.eps;
+  double sum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) sum[n] = 0.0;
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int row0 = wave * 256 + pass * 128;
+    const int64_t g0 = tile * kMpTileRows + row0; // global row of the pass's first row
+    if (g0 >= covered) break;                     // wave-uniform
+    f32x16 acc[4][NB];
+    batched_f32_pass<NB, KU, 0>(tbase + row0 + 4 * arow, g.col_stride, d, thetaL, arow, kk, acc);
+    // indicators of the two 64-row groups of this pass (a group never straddles a data block)
+    int8_t zc[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t gb = g0 + 64 * h;
+      const int64_t blk = gb >> p.block_shift;
+#pragma unroll
+      for (int n = 0; n < NB; n++) zc[h][n] = gb < covered ? z[blk * kBatchCols + n * 32 + arow] : (int8_t)1;
+    }
+
+    // accumulator (m, n, r) of lane l: tile row row0 + 4*i + m, i = (r&3) + 8*(r>>2) + 4*(l>>5);
+    // r < 8 is the first 64-row group of the pass, r >= 8 the second
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t gb = g0 + 64 * h;
+      const bool full = gb + 64 <= covered;
+#pragma unroll
+      for (int n = 0; n < NB; n++) {
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+          const int i = (rr & 3) + 8 * (rr >> 2) + 4 * kk;
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const float t = mpb_dark_term(acc[m][n][h * 8 + rr], epsf);
+            s += (full || gb + 4 * i + m < covered) ? t : 0.f;
+          }
+        }
+        sum[n] += zc[h][n] == 0 ? (double)s : 0.0;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < NB; n++) red[(wave * NB + n) * 64 + lane] = sum[n];
+  __syncthreads();
+  if ((int)threadIdx.x < NB * 32) {
+    const int n = threadIdx.x >> 5, c = threadIdx.x & 31;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s += red[(w * NB + n) * 64 + c] + red[(w * NB + n) * 64 + c + 32];
+    const int chain = n * 32 + c;
+    if (chain < p.K) partials[(int64_t)chain * pstride + tile] = s;
+  }
+}
+
+__device__ __forceinline__ double wave_total(double v)
+{
+  v = wave_sum_lane63(v);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// The rows of data block b against the theta of G chains c[0..G): per chain
+// the wave totals  lb = sum log(L - B)  (bright at entry)  and
+// rs = sum (log B - log L).
+template <int G>
+__device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, const TileGeom &gf,
+                                              const double *__restrict__ Xd, const TileGeom &gd,
+                                              const double *__restrict__ Theta, const float *__restrict__ Thetaf,
+                                              const MpbParams &p, int64_t covered, int64_t b, const int (&c)[kMpbGroup],
+                                              uint64_t bright_mask, int lane, double (&lb)[kMpbGroup], double (&rs)[kMpbGroup])
+{
+  constexpr int U = 4;
+  const int d = gf.d;
+  double s_lb[G], s_rs[G];
+#pragma unroll
+  for (int q = 0; q < G; q++) s_lb[q] = s_rs[q] = 0.0;
+
+  const int segs = p.block_rows >> 6;
+  for (int seg = 0; seg < segs; seg++) {
+    const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
+    if (first >= covered) break; // wave-uniform
+    const int64_t row = first + lane;
+    const float *pf = Xf + (row >> 10) * gf.tile_stride + (row & 1023);
+    const double *pd = Xd + (row >> 9) * gd.tile_stride + (row & 511);
+    float af[G];
+    double ad[G];
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      af[q] = 0.f;
+      ad[q] = 0.0;
+    }
+    int j0 = 0;
+    for (; j0 + U <= d; j0 += U) {
+      double xd[U];
+      float xf[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xd[u] = pd[(int64_t)(j0 + u) * gd.col_stride];
+        xf[u] = pf[(int64_t)(j0 + u) * gf.col_stride];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+          ad[q] = madd(ad[q], Theta[(int64_t)c[q] * d + j0 + u], xd[u]);
+          af[q] = fmaf(Thetaf[(int64_t)c[q] * d + j0 + u], xf[u], af[q]);
+        }
+    }
+    for (; j0 < d; j0++) {
+      const double xd = pd[(int64_t)j0 * gd.col_stride];
+      const float xf = pf[(int64_t)j0 * gf.col_stride];
+#pragma unroll
+      for (int q = 0; q < G; q++) {
+        ad[q] = madd(ad[q], Theta[(int64_t)c[q] * d + j0], xd);
+        af[q] = fmaf(Thetaf[(int64_t)c[q] * d + j0], xf, af[q]);
+      }
+    }
+    if (row < covered) {
+#pragma unroll
+      for (int q = 0; q < G; q++) {
+        const float sig_s = mhlik_sigmoidf_det(af[q]);
+        const double Bd = (double)sig_s - p.eps; // mcmc_mp.cu:63,146
+        const double L = 1.0 / (1.0 + exp(ad[q]));
+        if ((bright_mask >> c[q]) & 1ull) {
+          const float Bf = (float)Bd;
+          s_rs[q] += (double)logf(Bf) - log(L);
+          s_lb[q] += log(L - (double)Bf);
+        } else {
+          s_rs[q] += log(Bd) - log(L);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < G; q++) {
+    lb[q] = wave_total(s_lb[q]);
+    rs[q] = wave_total(s_rs[q]);
+  }
+}
+
+// grid = kMpbFixGroups x 256.  acc_out / cnt_out: [kMpbFixWaves][64].
+__global__ __launch_bounds__(kBlock) void mpb_fix_kernel(const float *__restrict__ Xf, TileGeom gf,
+                                                         const double *__restrict__ Xd, TileGeom gd,
+                                                         const double *__restrict__ Theta,
+                                                         const float *__restrict__ Thetaf, MpbParams p,
+                                                         const MpbChainArgs *__restrict__ ca, int8_t *__restrict__ z,
+                                                         double *__restrict__ acc_out, int32_t *__restrict__ cnt_out)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t all = (int64_t)p.blocks << p.block_shift;
+  const int64_t covered = all < p.n_rows ? all : p.n_rows;
+  const int my_choose = ca->choose[lane];
+  const uint64_t my_seed = ca->seed[lane];
+  double acc_b = 0.0;
+  int32_t cnt = 0;
+
+  for (int64_t b = wave_global; b < p.blocks; b += kMpbFixWaves) {
+    int8_t zc = lane < p.K ? z[b * kBatchCols + lane] : (int8_t)0;
+    const bool has_rows = (b << p.block_shift) < p.n_rows; // a block without rows keeps its indicator
+    const bool bright = zc != 0;
+    const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
+    const bool need = lane < p.K && has_rows && (bright || re);
+    uint64_t mask = __ballot(need);
+    const uint64_t bright_mask = __ballot(bright);
+    double my_rs = 0.0, my_lb = 0.0;
+    while (mask) {
+      int c[kMpbGroup];
+      int ng = 0;
+#pragma unroll
+      for (int q = 0; q < kMpbGroup; q++) {
+        if (mask) {
+          c[q] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
+          mask &= mask - 1;
+          ng++;
+        } else {
+          c[q] = c[0];
+        }
+      }
+      double lb[kMpbGroup], rs[kMpbGroup];
+      if (ng <= 2)
+        mpb_fix_group<2>(Xf, gf, Xd, gd, Theta, Thetaf, p, covered, b, c, bright_mask, lane, lb, rs);
+      else
+        mpb_fix_group<4>(Xf, gf, Xd, gd, Theta, Thetaf, p, covered, b, c, bright_mask, lane, lb, rs);
+#pragma unroll
+      for (int q = 0; q < kMpbGroup; q++)
+        if (q < ng && lane == c[q]) {
+          my_rs = rs[q];
+          my_lb = lb[q];
+        }
+    }
+    if (need) {
+      const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
+      const double p_bright = 1.0 - exp(my_rs);
+      const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
+      if (bright) acc_b += my_lb;
+      if (zn != zc) z[b * kBatchCols + lane] = zn;
+      zc = zn;
+    }
+    cnt += zc != 0 ? 1 : 0;
+  }
+  acc_out[(int64_t)wave_global * kBatchCols + lane] = acc_b;
+  cnt_out[(int64_t)wave_global * kBatchCols + lane] = cnt;
+}
+
+// grid = K.  res[k*4 + 0] = sum over blocks bright at entry (double)
+//            res[k*4 + 1] = sum over rows of blocks dark at entry, rounded to float
+//            res[k*4 + 2] = bright blocks after resampling, res[k*4 + 3] = dark blocks
+__global__ __launch_bounds__(kBlock) void mpb_final_kernel(const double *__restrict__ partials, int64_t pstride,
+                                                           int64_t tiles, const double *__restrict__ acc,
+                                                           const int32_t *__restrict__ cnt, int32_t blocks,
+                                                           double *__restrict__ res)
+{
+  __shared__ double lds[kBlock / kWave];
+  const int k = blockIdx.x;
+  double dark = strided_sum<kBlock>(partials + (int64_t)k * pstride, threadIdx.x, tiles);
+  double br = 0.0, nb = 0.0;
+  for (int w = threadIdx.x; w < kMpbFixWaves; w += kBlock) {
+    br += acc[(int64_t)w * kBatchCols + k];
+    nb += (double)cnt[(int64_t)w * kBatchCols + k];
+  }
+  dark = block_sum(dark, lds);
+  __syncthreads();
+  br = block_sum(br, lds);
+  __syncthreads();
+  nb = block_sum(nb, lds);
+  if (threadIdx.x == 0) {
+    res[k * 4 + 0] = br;
+    res[k * 4 + 1] = (double)(float)dark;
+    res[k * 4 + 2] = nb;
+    res[k * 4 + 3] = (double)blocks - nb;
+  }
+}
+
+} // namespace mhlik

@@ -150,6 +150,34 @@ class Likelihood:
         self._chk(self._lib.mhlik_mp_bound(self._ctx, _ptr(th), C.byref(s), C.byref(e)))
         return s.value, e.value
 
+    # -- mixed precision, K lock-step chains ----------------------------------
+    def mp_reset_batched(self, block_rows, blocks, K):
+        self._chk(self._lib.mhlik_mp_reset_batched(self._ctx, int(block_rows), int(blocks), int(K)))
+        self._mpb = (int(block_rows), int(blocks), int(K))
+
+    def mp_loglik_batched(self, Theta, resamp_factor, resamp_choose, u_seed, u_call, bound_eps):
+        """Theta [K, d]; resamp_choose, u_seed: one per chain.  Returns (values[K], bright[K], dark[K])."""
+        block_rows, blocks, K = self._mpb
+        Th = np.ascontiguousarray(Theta, dtype=np.float64)
+        if Th.shape != (K, self.n_cols):
+            raise ValueError("Theta must be [%d, %d]" % (K, self.n_cols))
+        ch = np.ascontiguousarray(resamp_choose, dtype=np.int32)
+        sd = np.ascontiguousarray(u_seed, dtype=np.uint64)
+        if ch.shape != (K,) or sd.shape != (K,):
+            raise ValueError("resamp_choose and u_seed must have one entry per chain")
+        st = L.MpBatch(block_rows, blocks, int(resamp_factor), K, _ptr(ch).value, _ptr(sd).value, int(u_call),
+                       float(bound_eps))
+        out = np.empty(K)
+        nb, nd = np.empty(K, dtype=np.int32), np.empty(K, dtype=np.int32)
+        self._chk(self._lib.mhlik_mp_loglik_batched(self._ctx, C.byref(st), _ptr(Th), _ptr(out), _ptr(nb), _ptr(nd)))
+        return out, nb, nd
+
+    def mp_indicators_batched(self):
+        block_rows, blocks, K = self._mpb
+        z = np.empty((K, blocks), dtype=np.int8)
+        self._chk(self._lib.mhlik_mp_indicators_batched(self._ctx, _ptr(z)))
+        return z
+
     # -- multi GPU ------------------------------------------------------------
     # ---- MH chain kept on the device (mhlik_chain_*) ----
     def chain_begin(self, theta0, prior_sd, dtype=np.float64):

@@ -1,0 +1,112 @@
+"""K-chain mixed-precision likelihood (BASELINE.json config 5: mcmc_mp with
+batched chains, X.Theta on MFMA) against the CPU restatement of the
+single-chain definition (oracle/mp_path.c) applied chain by chain, and against
+the single-chain HIP path.  "Parity unpinned" like the rest of the MP path:
+the reference's mcmc_mp is work in progress and commits no outputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_mp(X, Xf, th, block_rows, blocks, rf, rc, seed, call, eps, z):
+    L = O.lib()
+    L.oracle_mp_likelihood.restype = C.c_double
+    L.oracle_mp_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    nb, nd = C.c_int(), C.c_int()
+    N, d = X.shape
+    v = L.oracle_mp_likelihood(O.ptr(X), O.ptr(Xf), N, d, N, O.ptr(th), block_rows, blocks, rf, rc, seed, call, eps,
+                               O.ptr(z), C.byref(nb), C.byref(nd))
+    return v, nb.value, nd.value
+
+
+CASES = [
+    # N, d, block_rows, blocks (None = N // block_rows), K, resamp_factor
+    (16384, 8, 64, None, 64, 2),
+    (10000, 3, 64, None, 5, 4),      # ragged last tile, K < 32
+    (20000, 16, 256, None, 33, 3),   # K just over one 32-chain block
+    (8192, 5, 1024, None, 64, 2),
+    (5000, 7, 128, 30, 17, 2),       # blocks cover only part of the rows
+    (3000, 4, 64, 50, 8, 5),         # more blocks than rows: trailing blocks hold no rows
+    (9000, 130, 64, None, 40, 8),    # wide theta, odd tail columns
+]
+
+
+@pytest.mark.parametrize("N,d,block_rows,blocks,K,rf", CASES)
+def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, K, rf):
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(77, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    blocks = N // block_rows if blocks is None else blocks
+    eps = 1.7e-7
+    z = np.ones((K, blocks), dtype=np.int8)
+    seeds = np.arange(1000, 1000 + K, dtype=np.uint64)
+    rng = np.random.default_rng(1)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(Xf)
+        lk.mp_reset_batched(block_rows, blocks, K)
+        for call in range(5):
+            Th = rng.normal(0, 0.5 / np.sqrt(d), (K, d))
+            choose = rng.integers(0, rf, K).astype(np.int32)
+            got, gb, gd = lk.mp_loglik_batched(Th, rf, choose, seeds, call, eps)
+            for k in range(K):
+                want, wb, wd = _oracle_mp(X, Xf, Th[k], block_rows, blocks, rf, int(choose[k]), int(seeds[k]), call,
+                                          eps, z[k])
+                assert (gb[k], gd[k]) == (wb, wd), (call, k, gb[k], gd[k], wb, wd)
+                assert abs(got[k] - want) <= 2e-6 * abs(want), (call, k, got[k], want)
+            assert np.array_equal(lk.mp_indicators_batched(), z), call
+
+
+def test_mp_batched_chain_equals_single_chain_path():
+    """Chain k of the batched call = mhlik_mp_loglik with chain k's state."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, block_rows, K, rf, eps = 32768, 12, 64, 6, 4, 1.7e-7
+    blocks = N // block_rows
+    X = synthetic_host(5, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    rng = np.random.default_rng(2)
+    Ths = [rng.normal(0, 0.2, (K, d)) for _ in range(4)]
+    chooses = [rng.integers(0, rf, K).astype(np.int32) for _ in range(4)]
+    seeds = np.arange(7, 7 + K, dtype=np.uint64)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(Xf)
+        lk.mp_reset_batched(block_rows, blocks, K)
+        batched = [lk.mp_loglik_batched(Ths[c], rf, chooses[c], seeds, c, eps) for c in range(4)]
+        for k in range(K):
+            lk.mp_reset(block_rows, blocks)
+            for c in range(4):
+                v, nb, nd = lk.mp_loglik(Ths[c][k], block_rows, blocks, rf, int(chooses[c][k]), int(seeds[k]), c, eps)
+                bv, bb, bd = batched[c]
+                assert (bb[k], bd[k]) == (nb, nd)
+                assert abs(bv[k] - v) <= 2e-6 * abs(v)
+
+
+def test_mp_batched_rejects_bad_arguments():
+    from mcmc_amd import Likelihood
+    from mcmc_amd._lib import MhlikError
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 4096, 3
+    X = synthetic_host(1, N, d)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(np.asfortranarray(X.astype(np.float32)))
+        with pytest.raises(MhlikError):
+            lk.mp_reset_batched(96, 10, 4)  # not a power of two
+        with pytest.raises(MhlikError):
+            lk.mp_reset_batched(64, 10, 65)  # too many chains
+        lk.mp_reset_batched(64, N // 64, 4)
+        with pytest.raises(MhlikError):  # resamp_choose outside [0, factor)
+            lk.mp_loglik_batched(np.zeros((4, d)), 2, [0, 1, 2, 0], [1, 2, 3, 4], 0, 1e-7)
