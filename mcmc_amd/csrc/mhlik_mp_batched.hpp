@@ -17,19 +17,19 @@
 //                    data block is DARK for that chain.  MFMA-bound.
 //   mpb_fix_kernel   the double-precision correction, only for the (block,
 //                    chain) pairs that are bright or re-examined this call:
-//                    one wave per data block, one row per lane; the block's
-//                    double and float rows are loaded ONCE and dotted against
-//                    the theta of every chain that needs the block (<= 4 at a
-//                    time, theta through scalar loads).  Row terms are exactly
+//                    a work item is one data block x up to 4 chains that need
+//                    it, run by one wave, one row per lane: the block's double
+//                    and float rows are dotted against those chains' theta
+//                    (broadcast from LDS); the items of a block run side by
+//                    side in one workgroup so its rows come from HBM once.  Row terms are exactly
 //                    the single-chain kernel's (same madd / fmaf chains, the
 //                    shared deterministic float sigmoid); z is resampled with
 //                    P(bright) = 1 - exp(sum(log B - log L)).  Lane k of a wave
 //                    keeps chain k's running bright sum and bright count over
-//                    the blocks the wave visits (block b -> wave b mod 2048), so
-//                    there are no atomics and the result does not depend on
-//                    scheduling.
+//                    a fixed subset of the blocks, so there are no atomics and
+//                    the result does not depend on scheduling.
 //   mpb_final_kernel one workgroup per chain adds the tile partials of the dark
-//                    pass and the 2048 per-wave bright sums / counts.
+//                    pass and the 4096 per-wave bright sums / counts.
 //
 // Dark rows use fast float math (they are a float sum in the reference too);
 // everything that decides z or enters log(L - B) is the exact per-row
@@ -43,9 +43,11 @@
 
 namespace mhlik {
 
-constexpr int kMpbFixGroups = 512;                 // workgroups of the fix kernel (fixed: it shapes the sums)
-constexpr int kMpbFixWaves = kMpbFixGroups * 4;    // block b is visited by wave b mod kMpbFixWaves
+constexpr int kMpbFixGroups = 256;                 // workgroups of the fix kernel (fixed: it shapes the sums)
+constexpr int kMpbFixBlock = 1024;                 // 16 waves share one LDS copy of Theta
+constexpr int kMpbFixWaves = kMpbFixGroups * (kMpbFixBlock / kWave); // each wave visits a contiguous run of blocks
 constexpr int kMpbGroup = 4;                       // chains dotted against one load of a block's rows
+constexpr int kMpbU = 4;                           // columns per load batch of the fix kernel
 
 struct MpbParams {
   int32_t block_rows;   // 64 .. 1024, power of two
@@ -161,21 +163,48 @@ __device__ __forceinline__ double wave_total(double v)
   return __hiloint2double(hi, lo);
 }
 
+// One row of a (block, chain) pair that needs double precision: exactly the
+// per-row arithmetic of mp_tile_kernel / oracle/mp_path.c.  Kept out of line:
+// four inlined copies of exp + three logs cost more registers than the call.
+__device__ __noinline__ void mpb_pair_terms(float af, double ad, double eps, bool bright, double &s_rs, double &s_lb)
+{
+  const float sig_s = mhlik_sigmoidf_det(af);
+  const double Bd = (double)sig_s - eps; // mcmc_mp.cu:63,146
+  const double L = 1.0 / (1.0 + exp(ad));
+  if (bright) {
+    const float Bf = (float)Bd;
+    s_rs += (double)logf(Bf) - log(L);
+    s_lb += log(L - (double)Bf);
+  } else {
+    s_rs += log(Bd) - log(L);
+  }
+}
+
 // The rows of data block b against the theta of G chains c[0..G): per chain
 // the wave totals  lb = sum log(L - B)  (bright at entry)  and
-// rs = sum (log B - log L).
+// rs = sum (log B - log L).  thd / thf: Theta as [chain][d_pad] doubles /
+// floats, zero padded to a multiple of kMpbU columns (LDS, or global when it
+// does not fit); every lane reads the same address (broadcast).  The loads of
+// column chunk i+1 are in flight while chunk i is accumulated.
 template <int G>
 __device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, const TileGeom &gf,
-                                              const double *__restrict__ Xd, const TileGeom &gd,
-                                              const double *__restrict__ Theta, const float *__restrict__ Thetaf,
-                                              const MpbParams &p, int64_t covered, int64_t b, const int (&c)[kMpbGroup],
-                                              uint64_t bright_mask, int lane, double (&lb)[kMpbGroup], double (&rs)[kMpbGroup])
+                                              const double *__restrict__ Xd, const TileGeom &gd, const double *thd,
+                                              const float *thf, int d_pad, const MpbParams &p, int64_t covered,
+                                              int64_t b, const int (&c)[kMpbGroup], uint64_t bright_mask, int lane,
+                                              double (&lb)[kMpbGroup], double (&rs)[kMpbGroup])
 {
-  constexpr int U = 4;
+  constexpr int U = kMpbU;
   const int d = gf.d;
   double s_lb[G], s_rs[G];
 #pragma unroll
   for (int q = 0; q < G; q++) s_lb[q] = s_rs[q] = 0.0;
+  const double *td[G];
+  const float *tf[G];
+#pragma unroll
+  for (int q = 0; q < G; q++) {
+    td[q] = thd + c[q] * d_pad;
+    tf[q] = thf + c[q] * d_pad;
+  }
 
   const int segs = p.block_rows >> 6;
   for (int seg = 0; seg < segs; seg++) {
@@ -191,46 +220,51 @@ __device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, cons
       af[q] = 0.f;
       ad[q] = 0.0;
     }
+    double xd[U], nd[U];
+    float xf[U], nf[U];
+    const int csd = (int)gd.col_stride, csf = (int)gf.col_stride; // offsets inside one tile fit 32 bits
+    const int nfull = d / U;
     int j0 = 0;
-    for (; j0 + U <= d; j0 += U) {
-      double xd[U];
-      float xf[U];
+    if (nfull > 0) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        xd[u] = pd[(int64_t)(j0 + u) * gd.col_stride];
-        xf[u] = pf[(int64_t)(j0 + u) * gf.col_stride];
+        nd[u] = pd[u * csd];
+        nf[u] = pf[u * csf];
+      }
+    }
+    for (int bt = 0; bt < nfull; bt++, j0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xd[u] = nd[u];
+        xf[u] = nf[u];
+      }
+      if (bt + 1 < nfull) { // wave-uniform: the whole next batch or nothing
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          nd[u] = pd[(j0 + U + u) * csd];
+          nf[u] = pf[(j0 + U + u) * csf];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
         for (int q = 0; q < G; q++) {
-          ad[q] = madd(ad[q], Theta[(int64_t)c[q] * d + j0 + u], xd[u]);
-          af[q] = fmaf(Thetaf[(int64_t)c[q] * d + j0 + u], xf[u], af[q]);
+          ad[q] = madd(ad[q], td[q][j0 + u], xd[u]);
+          af[q] = fmaf(tf[q][j0 + u], xf[u], af[q]);
         }
     }
-    for (; j0 < d; j0++) {
-      const double xd = pd[(int64_t)j0 * gd.col_stride];
-      const float xf = pf[(int64_t)j0 * gf.col_stride];
+    for (; j0 < d; j0++) { // d % U leftover columns
+      const double x1 = pd[j0 * csd];
+      const float f1 = pf[j0 * csf];
 #pragma unroll
       for (int q = 0; q < G; q++) {
-        ad[q] = madd(ad[q], Theta[(int64_t)c[q] * d + j0], xd);
-        af[q] = fmaf(Thetaf[(int64_t)c[q] * d + j0], xf, af[q]);
+        ad[q] = madd(ad[q], td[q][j0], x1);
+        af[q] = fmaf(tf[q][j0], f1, af[q]);
       }
     }
     if (row < covered) {
 #pragma unroll
-      for (int q = 0; q < G; q++) {
-        const float sig_s = mhlik_sigmoidf_det(af[q]);
-        const double Bd = (double)sig_s - p.eps; // mcmc_mp.cu:63,146
-        const double L = 1.0 / (1.0 + exp(ad[q]));
-        if ((bright_mask >> c[q]) & 1ull) {
-          const float Bf = (float)Bd;
-          s_rs[q] += (double)logf(Bf) - log(L);
-          s_lb[q] += log(L - (double)Bf);
-        } else {
-          s_rs[q] += log(Bd) - log(L);
-        }
-      }
+      for (int q = 0; q < G; q++) mpb_pair_terms(af[q], ad[q], p.eps, (bright_mask >> c[q]) & 1ull, s_rs[q], s_lb[q]);
     }
   }
 #pragma unroll
@@ -240,16 +274,49 @@ __device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, cons
   }
 }
 
-// grid = kMpbFixGroups x 256.  acc_out / cnt_out: [kMpbFixWaves][64].
-__global__ __launch_bounds__(kBlock) void mpb_fix_kernel(const float *__restrict__ Xf, TileGeom gf,
-                                                         const double *__restrict__ Xd, TileGeom gd,
-                                                         const double *__restrict__ Theta,
-                                                         const float *__restrict__ Thetaf, MpbParams p,
-                                                         const MpbChainArgs *__restrict__ ca, int8_t *__restrict__ z,
-                                                         double *__restrict__ acc_out, int32_t *__restrict__ cnt_out)
+// grid = kMpbFixGroups x kMpbFixBlock.  acc_out / cnt_out: [kMpbFixWaves][64].
+// Theta: [K][d_pad] doubles then [K][d_pad] floats, zero padded; LDS_THETA: the
+// workgroup stages both into LDS (dynamic, K*d_pad*12 bytes).
+//
+// Each workgroup owns a fixed contiguous run of data blocks and walks it 16
+// blocks at a time (wave w <-> block b0 + w):
+//   1. lane k of wave w reads z[b0+w][k] and votes: which chains need block
+//      b0+w in double precision (bright, or dark and due for re-examination);
+//   2. the (block, up-to-4-chains) work items of the 16 blocks are dealt to the
+//      16 waves in order, so the items of one block run side by side and share
+//      its rows in L1/L2 (a block all 64 chains need is 16 items = the whole
+//      workgroup; 16 blocks one chain each need are one item per wave);
+//   3. wave w, lane k resamples z[b0+w][k] from the item results and adds to
+//      chain k's running bright sum / count.
+// Every sum is taken in an order fixed by (blocks, block_rows) alone.
+template <bool LDS_THETA>
+__global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__restrict__ Xf, TileGeom gf,
+                                                               const double *__restrict__ Xd, TileGeom gd,
+                                                               const double *__restrict__ Theta,
+                                                               const float *__restrict__ Thetaf, int d_pad,
+                                                               MpbParams p, const MpbChainArgs *__restrict__ ca,
+                                                               int8_t *__restrict__ z, double *__restrict__ acc_out,
+                                                               int32_t *__restrict__ cnt_out)
 {
-  const int lane = threadIdx.x & 63;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int NW = kMpbFixBlock / kWave; // 16 waves = 16 blocks per round
+  __shared__ unsigned long long need_mask[NW], bright_mask_s[NW];
+  __shared__ int item_begin[NW + 1];
+  __shared__ double res_rs[NW][kBatchCols], res_lb[NW][kBatchCols];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const double *thd = Theta;
+  const float *thf = Thetaf;
+  if constexpr (LDS_THETA) {
+    double *ld = reinterpret_cast<double *>(smem);
+    float *lf = reinterpret_cast<float *>(smem + sizeof(double) * (size_t)p.K * d_pad);
+    for (int i = threadIdx.x; i < p.K * d_pad; i += kMpbFixBlock) {
+      ld[i] = Theta[i];
+      lf[i] = Thetaf[i];
+    }
+    thd = ld;
+    thf = lf;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * NW + wave;
   const int64_t all = (int64_t)p.blocks << p.block_shift;
   const int64_t covered = all < p.n_rows ? all : p.n_rows;
   const int my_choose = ca->choose[lane];
@@ -257,49 +324,84 @@ __global__ __launch_bounds__(kBlock) void mpb_fix_kernel(const float *__restrict
   double acc_b = 0.0;
   int32_t cnt = 0;
 
-  for (int64_t b = wave_global; b < p.blocks; b += kMpbFixWaves) {
-    int8_t zc = lane < p.K ? z[b * kBatchCols + lane] : (int8_t)0;
-    const bool has_rows = (b << p.block_shift) < p.n_rows; // a block without rows keeps its indicator
+  const int64_t chunk = ((int64_t)p.blocks + kMpbFixGroups - 1) / kMpbFixGroups;
+  const int64_t wg_begin = blockIdx.x * chunk;
+  const int64_t wg_end = wg_begin + chunk < p.blocks ? wg_begin + chunk : p.blocks;
+  for (int64_t b0 = wg_begin; b0 < wg_end; b0 += NW) { // workgroup-uniform trip count
+    // ---- 1. votes -------------------------------------------------------------
+    const int64_t b = b0 + wave;
+    const bool live = b < wg_end;
+    int8_t zc = (live && lane < p.K) ? z[b * kBatchCols + lane] : (int8_t)0;
+    const bool has_rows = live && (b << p.block_shift) < p.n_rows; // a block without rows keeps its indicator
     const bool bright = zc != 0;
     const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
     const bool need = lane < p.K && has_rows && (bright || re);
-    uint64_t mask = __ballot(need);
-    const uint64_t bright_mask = __ballot(bright);
-    double my_rs = 0.0, my_lb = 0.0;
-    while (mask) {
+    const uint64_t mask = __ballot(need), bmask = __ballot(bright);
+    if (lane == 0) {
+      need_mask[wave] = mask;
+      bright_mask_s[wave] = bmask;
+    }
+    __syncthreads(); // also orders the LDS copy of Theta before its first use
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < NW; w++) {
+        item_begin[w] = t;
+        t += (__builtin_popcountll(need_mask[w]) + kMpbGroup - 1) / kMpbGroup;
+      }
+      item_begin[NW] = t;
+    }
+    __syncthreads();
+    // ---- 2. work items ----------------------------------------------------------
+    const int items = item_begin[NW];
+    for (int it = wave; it < items; it += NW) {
+      int w = 0;
+      while (item_begin[w + 1] <= it) w++; // wave-uniform
+      w = __builtin_amdgcn_readfirstlane(w);
+      int skip = (it - item_begin[w]) * kMpbGroup;
+      uint64_t m = need_mask[w];
+      while (skip-- > 0) m &= m - 1;
       int c[kMpbGroup];
       int ng = 0;
 #pragma unroll
       for (int q = 0; q < kMpbGroup; q++) {
-        if (mask) {
-          c[q] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
-          mask &= mask - 1;
+        if (m) {
+          c[q] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
+          m &= m - 1;
           ng++;
         } else {
           c[q] = c[0];
         }
       }
+      const uint64_t bm = bright_mask_s[w];
       double lb[kMpbGroup], rs[kMpbGroup];
-      if (ng <= 2)
-        mpb_fix_group<2>(Xf, gf, Xd, gd, Theta, Thetaf, p, covered, b, c, bright_mask, lane, lb, rs);
+      if (ng <= 1)
+        mpb_fix_group<1>(Xf, gf, Xd, gd, thd, thf, d_pad, p, covered, b0 + w, c, bm, lane, lb, rs);
+      else if (ng <= 2)
+        mpb_fix_group<2>(Xf, gf, Xd, gd, thd, thf, d_pad, p, covered, b0 + w, c, bm, lane, lb, rs);
       else
-        mpb_fix_group<4>(Xf, gf, Xd, gd, Theta, Thetaf, p, covered, b, c, bright_mask, lane, lb, rs);
+        mpb_fix_group<4>(Xf, gf, Xd, gd, thd, thf, d_pad, p, covered, b0 + w, c, bm, lane, lb, rs);
+      if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < kMpbGroup; q++)
-        if (q < ng && lane == c[q]) {
-          my_rs = rs[q];
-          my_lb = lb[q];
-        }
+        for (int q = 0; q < kMpbGroup; q++)
+          if (q < ng) {
+            res_rs[w][c[q]] = rs[q];
+            res_lb[w][c[q]] = lb[q];
+          }
+      }
     }
+    __syncthreads();
+    // ---- 3. resample, accumulate -------------------------------------------------
     if (need) {
       const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
-      const double p_bright = 1.0 - exp(my_rs);
+      const double p_bright = 1.0 - exp(res_rs[wave][lane]);
       const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
-      if (bright) acc_b += my_lb;
+      if (bright) acc_b += res_lb[wave][lane];
       if (zn != zc) z[b * kBatchCols + lane] = zn;
       zc = zn;
     }
     cnt += zc != 0 ? 1 : 0;
+    // the next round's writes to the LDS tables come after its first barrier,
+    // which every wave reaches only after this point
   }
   acc_out[(int64_t)wave_global * kBatchCols + lane] = acc_b;
   cnt_out[(int64_t)wave_global * kBatchCols + lane] = cnt;
