@@ -90,6 +90,16 @@ float gpu_likelihood_f(mhlik_ctx *lik, mcmc_str mcin, float *samplesf, out_str *
 void mcmc_amd_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mcmc_str mcin, mcmc_tune_str mct,
                                  double *samples, double *burn, int *accepted, int use_f32);
 
+/* K mixed-precision chains in lock step, one mhlik_mp_loglik_batched call per
+ * iteration (float X.Theta pass on MFMA + double correction of bright /
+ * re-examined blocks).  Chain k is mp_sampler run with generator r[k].
+ * samples [K][Ns][d]; burn [K][burnin][d]; accepted [K]; bright_blocks [K] or
+ * NULL.  shared_phase != 0: all chains re-examine the phase chain 0 drew (same
+ * random streams, 1/ResampFactor of the double matrix read per iteration). */
+void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *mpVar, mcmc_str mcin,
+                                    mcmc_tune_str mct, double *samples, double *burn, int *accepted,
+                                    double lhoodBound, int shared_phase, int *bright_blocks);
+
 /* By default every sampler / tuner call uploads data.data (or data.dataf) to
  * a fresh context and frees it on return, as the reference does
  * (mcmc_gpu.cu:53-58, 78-81).  A context attached here is used instead by

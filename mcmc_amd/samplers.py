@@ -273,6 +273,28 @@ def multichain_sampler(lik, seeds, Ns, burnin, rwsd, use_f32=False):
     return dict(samples=samples, burn=burn, accepted=acc)
 
 
+def mp_multichain_sampler(lik, seeds, Ns, burnin, rwsd, block_rows, blocks, resamp_factor, bound, shared_phase=False):
+    """K lock-step mixed-precision chains on an existing Likelihood context
+    (both matrices, segments=1); chain k is mp_sampler with generator seeds[k]."""
+    S = load_samplers()
+    K, d = len(seeds), lik.n_cols
+    rngs = [Rng(s) for s in seeds]
+    arr = (C.c_void_p * K)(*[r.r for r in rngs])
+    samples = np.zeros((K, Ns, d))
+    burn = np.zeros((K, max(burnin, 1), d))
+    acc = np.zeros(K, dtype=np.int32)
+    bright = np.zeros(K, dtype=np.int32)
+    mcin = mcmc_str(ddata=d, Nd=lik.n_rows, Ns=Ns, burnin=burnin, impl=IMPL_MP)
+    mp = mp_str(dataBlocks=blocks, dataBlockSz=block_rows, ResampFactor=resamp_factor)
+    S.mcmc_amd_mp_multichain_sampler.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(mp_str), mcmc_str,
+                                                 mcmc_tune_str, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                 C.c_int, C.c_void_p]
+    S.mcmc_amd_mp_multichain_sampler(lik.handle, K, arr, C.byref(mp), mcin, mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd),
+                                     _ptr(samples), _ptr(burn), _ptr(acc), float(bound), int(shared_phase),
+                                     _ptr(bright))
+    return dict(samples=samples, burn=burn, accepted=acc, bright=bright, mp=mp)
+
+
 def get_ess(samples, max_lag):
     S = load_samplers()
     s = np.ascontiguousarray(samples, dtype=np.float64)

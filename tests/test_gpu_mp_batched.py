@@ -110,3 +110,49 @@ def test_mp_batched_rejects_bad_arguments():
         lk.mp_reset_batched(64, N // 64, 4)
         with pytest.raises(MhlikError):  # resamp_choose outside [0, factor)
             lk.mp_loglik_batched(np.zeros((4, d)), 2, [0, 1, 2, 0], [1, 2, 3, 4], 0, 1e-7)
+
+
+def test_mp_multichain_sampler_reproduces_mp_sampler_per_chain():
+    """Chain k of the lock-step sampler walks the chain mp_sampler walks with
+    the same generator seed: same proposals, same accept decisions, same
+    samples (the dark float sums agree to ~1e-7 relative, far inside the
+    accept margins of this short run)."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, Ns, burnin = 8192, 4, 60, 20
+    X = synthetic_host(12345, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    seeds = [3, 4, 3]
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(Xf)
+        out = S.mp_multichain_sampler(lk, seeds, Ns, burnin, 0.05, 64, N // 64, 4, 1.7e-7)
+    assert np.isfinite(out["samples"]).all()
+    assert np.array_equal(out["samples"][0], out["samples"][2])  # same seed, same chain
+    assert not np.array_equal(out["samples"][0], out["samples"][1])
+    for k in (0, 1):
+        ref = S.mp_sampler(X, seeds[k], Ns, burnin, 0.05, block_rows=64, blocks=N // 64, resamp_factor=4, bound=1.7e-7,
+                           trace=False)
+        assert np.array_equal(out["samples"][k], ref["samples"]), k
+        assert np.array_equal(out["burn"][k][1:], ref["burn"][1:]), k
+        assert out["accepted"][k] == round(ref["acceptance"] * Ns)
+
+
+def test_mp_multichain_sampler_shared_phase_runs_and_keeps_streams():
+    from mcmc_amd import Likelihood
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 8192, 4
+    X = synthetic_host(12345, N, d)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(np.asfortranarray(X.astype(np.float32)))
+        a = S.mp_multichain_sampler(lk, [3, 4, 5], 40, 10, 0.05, 64, N // 64, 8, 1.7e-7, shared_phase=True)
+        b = S.mp_multichain_sampler(lk, [3, 4, 5], 40, 10, 0.05, 64, N // 64, 8, 1.7e-7, shared_phase=False)
+    assert np.isfinite(a["samples"]).all()
+    # chain 0 re-examines its own phase either way: identical trajectory
+    assert np.array_equal(a["samples"][0], b["samples"][0])
+    assert (a["bright"] >= 0).all() and (a["bright"] <= N // 64).all()
