@@ -129,10 +129,29 @@ __global__ __launch_bounds__(kBlock) void mp_tile_kernel(const float *__restrict
   if (need_dp) {
     const int64_t dtile = tile * 2 + (lane_row >= 512 ? 1 : 0);
     const double *tb = Xd + dtile * gd.tile_stride + (lane_row & 511);
-    for (int j = 0; j < d; j++) {
-      const double *col = tb + (int64_t)j * gd.col_stride;
+    constexpr int UD = 8; // columns in flight: 16 independent 16-byte loads per lane
+    int j0 = 0;
+    for (; j0 + UD <= d; j0 += UD) {
+      V2 a[UD], c[UD];
+#pragma unroll
+      for (int u = 0; u < UD; u++) {
+        const double *col = tb + (int64_t)(j0 + u) * gd.col_stride;
+        a[u] = load16<double, true>(col);
+        c[u] = load16<double, true>(col + 2);
+      }
+#pragma unroll
+      for (int u = 0; u < UD; u++) {
+        const double t = theta.v[j0 + u];
+        accd[0] = madd(accd[0], t, a[u][0]);
+        accd[1] = madd(accd[1], t, a[u][1]);
+        accd[2] = madd(accd[2], t, c[u][0]);
+        accd[3] = madd(accd[3], t, c[u][1]);
+      }
+    }
+    for (; j0 < d; j0++) {
+      const double *col = tb + (int64_t)j0 * gd.col_stride;
       V2 a = load16<double, true>(col), c = load16<double, true>(col + 2);
-      const double t = theta.v[j];
+      const double t = theta.v[j0];
       accd[0] = madd(accd[0], t, a[0]);
       accd[1] = madd(accd[1], t, a[1]);
       accd[2] = madd(accd[2], t, c[0]);
@@ -206,33 +225,76 @@ __global__ __launch_bounds__(kBlock) void mp_tile_kernel(const float *__restrict
   }
 }
 
-// Single workgroup: add the block records in a fixed order.
+// Add the block records in a fixed order, in two stages (a single workgroup
+// walking 1e5+ records is latency-bound): workgroup g of kMpReduceGroups sums
+// its contiguous run of records -- thread i takes records i, i+256, ... of the
+// run, doubles for blocks bright at entry, a float accumulator for blocks dark
+// at entry, eight loads in flight -- then the fixed block tree; the final
+// single workgroup adds the kMpReduceGroups partials.
 //   res[0] = red_d (double sum over blocks bright at entry)
 //   res[1] = red_f (float sum over blocks dark at entry)
 //   res[2] = bright count after resampling, res[3] = dark count
+constexpr int kMpReduceGroups = 256;
+
 __global__ __launch_bounds__(kBlock) void mp_reduce_kernel(const MpBlockOut *__restrict__ out,
                                                            const int8_t *__restrict__ z, int32_t blocks,
-                                                           double *__restrict__ res)
+                                                           double *__restrict__ part /* [3][kMpReduceGroups] */)
 {
   __shared__ double lds[kBlock / kWave];
+  const int per = (blocks + kMpReduceGroups - 1) / kMpReduceGroups;
+  const int lo = blockIdx.x * per;
+  const int hi = lo + per < blocks ? lo + per : blocks;
   double sd = 0.0, nb = 0.0;
   float sf = 0.f;
-  for (int b = threadIdx.x; b < blocks; b += kBlock) {
-    const MpBlockOut o = out[b];
-    if (o.was_bright)
-      sd += o.value;
-    else
-      sf += (float)o.value;
-    nb += (z[b] != 0) ? 1.0 : 0.0;
+  for (int b0 = lo + (int)threadIdx.x; b0 < hi; b0 += kBlock * 8) {
+    MpBlockOut o[8];
+    int8_t zz[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int b = b0 + u * kBlock;
+      if (b < hi) {
+        o[u] = out[b];
+        zz[u] = z[b];
+      } else {
+        o[u].value = 0.0;
+        o[u].was_bright = 0;
+        zz[u] = 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (o[u].was_bright)
+        sd += o[u].value;
+      else
+        sf += (float)o[u].value;
+      nb += (zz[u] != 0) ? 1.0 : 0.0;
+    }
   }
   double t = block_sum(sd, lds);
   __syncthreads();
-  double tf = block_sum((double)sf, lds); // partial float sums added in double, rounded once below
+  double tf = block_sum((double)sf, lds); // per-thread float sums added in double
   __syncthreads();
   double tb = block_sum(nb, lds);
   if (threadIdx.x == 0) {
+    part[blockIdx.x] = t;
+    part[kMpReduceGroups + blockIdx.x] = tf;
+    part[2 * kMpReduceGroups + blockIdx.x] = tb;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mp_reduce_final_kernel(const double *__restrict__ part, int32_t blocks,
+                                                                 double *__restrict__ res)
+{
+  __shared__ double lds[kBlock / kWave];
+  static_assert(kMpReduceGroups == kBlock, "one partial per thread");
+  double t = block_sum(part[threadIdx.x], lds);
+  __syncthreads();
+  double tf = block_sum(part[kMpReduceGroups + threadIdx.x], lds);
+  __syncthreads();
+  double tb = block_sum(part[2 * kMpReduceGroups + threadIdx.x], lds);
+  if (threadIdx.x == 0) {
     res[0] = t;
-    res[1] = (double)(float)tf;
+    res[1] = (double)(float)tf; // rounded to float once
     res[2] = tb;
     res[3] = (double)blocks - tb;
   }
