@@ -253,6 +253,19 @@ int mhlik_chain_run_f32(mhlik_ctx *ctx, mhlik_chain_batch_f32 *batch);
 int mhlik_chain_state_f64(mhlik_ctx *ctx, double *current, double *cposterior);
 int mhlik_chain_state_f32(mhlik_ctx *ctx, float *current, float *cposterior);
 
+/* ---- chain statistics on the device ---------
+ *
+ * circular_autocorrelation (src/util/processing_util.c:206-260, float twin
+ * :262-316) as tune_ess_gpu / tune_ess_sp call it after every trial chain
+ * (src/mcmc_gpu/mcmc_gpu.cu:260-377): samples is a host array [n][d]
+ * (row-major: one chain state per row); out_v[k], k < lags, gets
+ * prod_i acc_i(k) / (var_i * (n - k)); *sum (may be NULL) the sum of out_v[1..].
+ * Needs no design matrix; uses the context's device and stream. */
+int mhlik_autocorrelation_f64(mhlik_ctx *ctx, const double *samples, int64_t n, int32_t d, int32_t lags,
+                              double *out_v, double *sum);
+int mhlik_autocorrelation_f32(mhlik_ctx *ctx, const float *samples, int64_t n, int32_t d, int32_t lags,
+                              float *out_v, float *sum);
+
 /* ---- multi-GPU (no counterpart: the reference is single-GPU, mcmc_gpu.cu:28) */
 
 /* Rank 0 makes an id, the host layer ships the bytes to every rank (e.g. a

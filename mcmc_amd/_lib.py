@@ -126,6 +126,8 @@ _SIGS = [
     ("mhlik_chain_run_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
     ("mhlik_chain_state_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("mhlik_chain_state_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    ("mhlik_autocorrelation_f64", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
+    ("mhlik_autocorrelation_f32", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_float)]),
     ("mhlik_comm_make_id", C.c_int, [_P]),
     ("mhlik_comm_init", C.c_int, [_P, _P]),
     ("mhlik_last_segment_sums", C.c_int, [_P, _P]),

@@ -21,6 +21,7 @@
 #include "mhlik_mp.hpp"
 #include "mhlik_mp_batched.hpp"
 #include "mhlik_chain.hpp"
+#include "mhlik_stats.hpp"
 #include "mhlik_synth.h"
 
 using namespace mhlik;
@@ -162,6 +163,9 @@ struct mhlik_ctx {
   float *mpb_thetaf = nullptr;
   void *mpb_args = nullptr;     // device MpbChainArgs
   double *mpb_res = nullptr, *mpb_res_dev = nullptr; // pinned host [64][4] and its device view
+
+  void *stats_buf = nullptr; // chain statistics scratch (mhlik_stats.hpp)
+  size_t stats_cap = 0;
 
   ncclComm_t comm = nullptr;
   ChainHost chain;
@@ -671,6 +675,7 @@ void mhlik_destroy(mhlik_ctx *c)
   if (c->mp_z) (void)hipFree(c->mp_z);
   if (c->mp_out) (void)hipFree(c->mp_out);
   mpb_free(c);
+  if (c->stats_buf) (void)hipFree(c->stats_buf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -851,3 +856,4 @@ int mhlik_comm_init(mhlik_ctx *c, const uint8_t id[MHLIK_COMM_ID_BYTES])
 #include "mhlik_mp_abi.inc"
 #include "mhlik_mp_batched_abi.inc"
 #include "mhlik_chain_abi.inc"
+#include "mhlik_stats_abi.inc"

@@ -247,7 +247,11 @@ void tune_ess_gpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, 
   for (int a = 0; a < 9; a++) {
     MH_SAY("\tStarting tuning for target ratio = %4.3f. Current rwsd = %5.3f\n", target_a[a], sd);
     search_sd(lik, r, v, mcin, chain_length, runs, target_a[a], &loc, samples, initCond, &sd, &best_sd, "\t\t");
-    double circ = circular_autocorrelation(autocorr, samples, mcin.ddata, chain_length, lagidx);
+    double circ = 0; /* circular_autocorrelation on the device (host loop: MCMC_AMD_HOST_STATS=1) */
+    if (mh_device_stats_enabled())
+      MH_CHECK(mhlik_autocorrelation_f64(lik, samples, chain_length, mcin.ddata, lagidx, autocorr, &circ), lik);
+    else
+      circ = circular_autocorrelation(autocorr, samples, mcin.ddata, chain_length, lagidx);
     double ess = chain_length / (1 + 2 * circ);
     if (ess > max_ess) {
       max_ess = ess;

@@ -296,7 +296,11 @@ void tune_ess_sp(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, g
   for (int a = 0; a < 9; a++) {
     MH_SAY("\tStarting tuning for target ratio = %4.3f. Current rwsdf = %5.3f\n", target_a[a], sd);
     search_sd_f(lik, r, v, mcin, chain_length, runs, target_a[a], &loc, samples, initCond, &sd, &best_sd, "\t\t");
-    float circ = circular_autocorrelation_sp(autocorr, samples, mcin.ddata, chain_length, lagidx);
+    float circ = 0; /* circular_autocorrelation_sp on the device (host loop: MCMC_AMD_HOST_STATS=1) */
+    if (mh_device_stats_enabled())
+      MH_CHECK(mhlik_autocorrelation_f32(lik, samples, chain_length, mcin.ddata, lagidx, autocorr, &circ), lik);
+    else
+      circ = circular_autocorrelation_sp(autocorr, samples, mcin.ddata, chain_length, lagidx);
     float ess = chain_length / (1 + 2 * circ);
     if (ess > max_ess) {
       max_ess = ess;

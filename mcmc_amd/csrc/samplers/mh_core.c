@@ -180,6 +180,13 @@ int mh_device_chain_enabled(void)
   return (e && e[0] == '1') ? 0 : 1;
 }
 
+/* tune_ess_*: autocorrelation of the trial chains on the device (row f4) */
+int mh_device_stats_enabled(void)
+{
+  const char *e = getenv("MCMC_AMD_HOST_STATS");
+  return (e && e[0] == '1') ? 0 : 1;
+}
+
 #define MH_CHAIN_MAX_BATCH 65536
 
 void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,

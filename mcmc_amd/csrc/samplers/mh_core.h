@@ -47,6 +47,7 @@ double mh_log_prior_d(const double *sample, int d, int prior_sd);
  * n rows of d, the state after each iteration (NULL: not kept).  v.current /
  * loc->cposterior are the state on entry and on return. */
 int mh_device_chain_enabled(void);
+int mh_device_stats_enabled(void);
 void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,
                       double *rows_out, int *accepted, out_str *res, int prior_sd);
 

@@ -221,6 +221,19 @@ class Likelihood:
             self._chk(self._lib.mhlik_chain_state_f32(self._ctx, _ptr(cur), C.byref(cp)))
         return cur, cp.value
 
+    # -- chain statistics ---------------------------------------------------------
+    def autocorrelation(self, samples, lags, dtype=np.float64):
+        """circular_autocorrelation on the device: returns (out_v[lags], sum of out_v[1:])."""
+        m = np.ascontiguousarray(samples, dtype=dtype)
+        out = np.empty(lags, dtype=dtype)
+        if dtype == np.float64:
+            s = C.c_double()
+            self._chk(self._lib.mhlik_autocorrelation_f64(self._ctx, _ptr(m), m.shape[0], m.shape[1], lags, _ptr(out), C.byref(s)))
+        else:
+            s = C.c_float()
+            self._chk(self._lib.mhlik_autocorrelation_f32(self._ctx, _ptr(m), m.shape[0], m.shape[1], lags, _ptr(out), C.byref(s)))
+        return out, s.value
+
     @staticmethod
     def make_comm_id():
         lib = L.load_mhlik()

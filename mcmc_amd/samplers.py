@@ -255,6 +255,19 @@ def tune_target_a_gpu_v2(X, seed, burnin, rwsd, ratio=0.25, max_reps=40, rng=Non
     return mct.rwsd
 
 
+def tune_ess_gpu(X, seed, burnin, rwsd, length, rng=None):
+    """tune_ess_gpu (mcmc_gpu.h:32): returns the selected random-walk sd."""
+    S = load_samplers()
+    X = np.asfortranarray(X, dtype=np.float64)
+    N, d = X.shape
+    init = np.zeros(d)
+    mcin = mcmc_str(ddata=d, Nd=N, Ns=1, burnin=burnin, impl=IMPL_GPU)
+    mct = mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
+    rng = rng or Rng(seed)
+    S.tune_ess_gpu(data_str(data=_ptr(X).value), rng.r, mcin, C.byref(mct), gpu_v_str(), _ptr(init), int(length))
+    return mct.rwsd
+
+
 def multichain_sampler(lik, seeds, Ns, burnin, rwsd, use_f32=False):
     """K lock-step chains on an existing Likelihood context (batched MFMA pass
     per iteration); chain k uses its own generator seeded seeds[k]."""
