@@ -333,6 +333,22 @@ __global__ __launch_bounds__(kBlock) void synth_fill_kernel(T *__restrict__ X, T
   }
 }
 
+// Upload staging -> tiled layout: workgroup b moves tile (tile0 + b) out of a
+// column-major chunk (leading dimension stage_ld, the chunk's first row is the
+// tile's row 0 for b = 0).  Rows past the tile's valid count stay zero.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void retile_kernel(const T *__restrict__ stage, int64_t stage_ld, T *__restrict__ X,
+                                                        TileGeom g, int64_t tile0, const int32_t *__restrict__ tile_valid,
+                                                        int tile_rows)
+{
+  const int64_t tile = tile0 + blockIdx.x;
+  const int valid = tile_valid[tile];
+  const T *src = stage + (int64_t)blockIdx.x * tile_rows;
+  T *dst = X + tile * g.tile_stride;
+  for (int j = 0; j < g.d; j++)
+    for (int r = threadIdx.x; r < valid; r += kBlock) dst[(int64_t)j * g.col_stride + r] = src[(int64_t)j * stage_ld + r];
+}
+
 template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
 void launch_tile(mhlik_ctx *c, const Store &s, const ThetaArg<T> &th, const T *theta_g, double *partials, T *rowdots)
 {
@@ -514,13 +530,37 @@ template <typename T> int upload_impl(mhlik_ctx *c, const T *X, int64_t ld, int6
   if (rc) return rc;
   Store &s = store_of<T>(c);
   const int d = c->cfg.n_cols;
-  for (int64_t t = 0; t < s.ntiles; t++) {
-    const T *src = X + (s.h_row0[t] - row0);
-    T *dst = (T *)s.X + tile_offset(s, t);
-    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)s.col_stride * sizeof(T), src, (size_t)ld * sizeof(T),
-                               (size_t)s.h_valid[t] * sizeof(T), (size_t)d, hipMemcpyHostToDevice, c->stream));
+  // Large strided pieces over PCIe into a column-major staging buffer (one
+  // 2-D copy per chunk of rows: d pieces of chunk*sizeof(T) bytes), then a
+  // device kernel moves the chunk into the tiled layout at HBM speed.  A
+  // per-tile 2-D copy (d pieces of 4 KiB each) runs at < 0.5 GB/s.
+  const int64_t chunk_tiles = s.ntiles < 2048 ? s.ntiles : 2048; // <= 1M rows (f64) per chunk
+  T *stage = nullptr;
+  if (chunk_tiles > 0) HIPCHK(c, hipMalloc((void **)&stage, sizeof(T) * (size_t)chunk_tiles * s.tile_rows * d));
+  TileGeom g{s.tile_stride, s.col_stride, d};
+  for (size_t si = 0; si < s.h_segs.size(); si++) {
+    const SegDesc &sd = s.h_segs[si];
+    const Segment &sg = c->segs[si];
+    for (int64_t t0 = 0; t0 < sd.tile_count; t0 += chunk_tiles) {
+      const int64_t nt = sd.tile_count - t0 < chunk_tiles ? sd.tile_count - t0 : chunk_tiles;
+      const int64_t first = sg.row_begin + t0 * s.tile_rows; // global row of the chunk's first row
+      int64_t rows = sg.rows - t0 * s.tile_rows;
+      if (rows > nt * s.tile_rows) rows = nt * s.tile_rows;
+      const int64_t stage_ld = nt * s.tile_rows;
+      hipError_t e = hipMemcpy2DAsync(stage, (size_t)stage_ld * sizeof(T), X + (first - row0), (size_t)ld * sizeof(T),
+                                      (size_t)rows * sizeof(T), (size_t)d, hipMemcpyHostToDevice, c->stream);
+      if (e != hipSuccess) {
+        (void)hipFree(stage);
+        return fail(c, MHLIK_EHIP, "hipMemcpy2DAsync (upload) failed: %s", hipGetErrorString(e));
+      }
+      hipLaunchKernelGGL(retile_kernel<T>, dim3((unsigned)nt), dim3(kBlock), 0, c->stream, (const T *)stage, stage_ld,
+                         (T *)s.X, g, sd.tile_begin + t0, s.tile_valid, s.tile_rows);
+    }
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  if (stage) (void)hipFree(stage);
+  if (e2 != hipSuccess) return fail(c, MHLIK_EHIP, "upload failed: %s", hipGetErrorString(e2));
+  HIPCHK(c, hipGetLastError());
   s.has_data = true;
   return MHLIK_OK;
 }
