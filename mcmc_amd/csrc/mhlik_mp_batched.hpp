@@ -123,19 +123,25 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_kernel(const float *__rest
     // r < 8 is the first 64-row group of the pass, r >= 8 the second
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int64_t gb = g0 + 64 * h;
-      const bool full = gb + 64 <= covered;
+      const int64_t left = covered - (g0 + 64 * h); // rows of this group inside the considered blocks
+      const int lim = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+      const int lbase = 16 * kk;                     // group row of (rr = 0, m = 0) in this lane
 #pragma unroll
       for (int n = 0; n < NB; n++) {
         float s = 0.f;
+        if (lim == 64) { // wave-uniform
 #pragma unroll
-        for (int rr = 0; rr < 8; rr++) {
-          const int i = (rr & 3) + 8 * (rr >> 2) + 4 * kk;
+          for (int rr = 0; rr < 8; rr++)
 #pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const float t = mpb_dark_term(acc[m][n][h * 8 + rr], epsf);
-            s += (full || gb + 4 * i + m < covered) ? t : 0.f;
-          }
+            for (int m = 0; m < 4; m++) s += mpb_dark_term(acc[m][n][h * 8 + rr], epsf);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+              const float t = mpb_dark_term(acc[m][n][h * 8 + rr], epsf);
+              s += (lbase + 4 * ((rr & 3) + 8 * (rr >> 2)) + m < lim) ? t : 0.f;
+            }
         }
         sum[n] += zc[h][n] == 0 ? (double)s : 0.0;
       }

@@ -49,7 +49,8 @@ int main(int argc, char **argv)
     double *P; CK(hipMalloc(&P, sizeof(double) * ntiles * 64));
     TileGeom g{(int64_t)tile_rows * d, tile_rows, d};
     size_t lds = sizeof(float) * d * 64 + sizeof(double) * 4 * 2 * 64;
-#define RUN32(EXPV, label) { auto k = lik_batched_f32_kernel<2, 4, EXPV>; \
+#define RUN32(EXPV, label) RUN32K(8, EXPV, label)
+#define RUN32K(KUV, EXPV, label) { auto k = lik_batched_f32_kernel<2, KUV, EXPV>; \
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
       printf("f32 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
@@ -57,6 +58,9 @@ int main(int argc, char **argv)
     RUN32(1, "no transcendental epilogue")
     RUN32(2, "no global loads in k-loop")
     RUN32(3, "neither")
+    RUN32K(4, 0, "KU=4")
+    RUN32K(16, 0, "KU=16")
+    RUN32(0, "current (again)")
     {
       std::vector<double> h1((size_t)ntiles * 64);
       auto k1 = lik_batched_f32_kernel<2, 4, 0>;
@@ -82,23 +86,7 @@ int main(int argc, char **argv)
           double e = fabs(a - b2) / fabs(a); if (e > worst) worst = e; } \
         printf("f32 %-28s %.3f ms  %.1f TF   max rel diff vs v1 per tile %.2e\n", label, ms, flops / ms / 1e9, worst); \
         CK(hipFree(th2)); }
-      RUNV2X(8, 0, "v2 persistent KU=8")
-      RUNV2X(8, 1, "v2 KU=8 no epilogue")
-      RUNV2X(8, 4, "v2 KU=8 cache-resident")
-      RUNV2X(8, 5, "v2 KU=8 cache-res no epi")
       RUNV2X(4, 32, "v2 glds KU=4")
-      RUNV2X(4, 48, "v2 glds KU=4 AGPR")
-      RUNV2X(4, 33, "v2 glds KU=4 no epi")
-      RUNV2Y(8, 32, 1, "v2 glds KU=8 1 wave/SIMD")
-      RUNV2Y(8, 0, 1, "v2 one wave/SIMD")
-      RUNV2Y(8, 16, 1, "v2 one wave/SIMD AGPR")
-      RUNV2Y(8, 17, 1, "v2 one wave/SIMD AGPR noepi")
-      RUNV2X(8, 16, "v2 AGPR acc")
-      RUNV2X(8, 17, "v2 AGPR acc no epi")
-      RUNV2X(4, 16, "v2 AGPR acc KU=4")
-      RUNV2X(8, 9, "v2 loads not waited, no epi")
-      RUNV2X(8, 13, "v2 same, cache-resident")
-      RUNV2X(4, 0, "v2 persistent KU=4")
       CK(hipFree(P2));
     }
     CK(hipFree(X)); CK(hipFree(tv)); CK(hipFree(th)); CK(hipFree(P));
@@ -113,7 +101,8 @@ int main(int argc, char **argv)
     double *P; CK(hipMalloc(&P, sizeof(double) * ntiles * 64));
     TileGeom g{(int64_t)tile_rows * d, tile_rows, d};
     size_t lds = sizeof(double) * d * 64 + sizeof(double) * 4 * 4 * 64;
-#define RUN64(EXPV, label) { auto k = lik_batched_f64_kernel<4, 2, EXPV>; \
+#define RUN64(EXPV, label) RUN64K(2, EXPV, label)
+#define RUN64K(KUV, EXPV, label) { auto k = lik_batched_f64_kernel<4, KUV, EXPV>; \
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
       printf("f64 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
@@ -122,6 +111,7 @@ int main(int argc, char **argv)
     RUN64(1, "no transcendental epilogue")
     RUN64(2, "no global loads in k-loop")
     RUN64(3, "neither")
+    RUN64K(4, 0, "KU=4")
   }
   return 0;
 }
