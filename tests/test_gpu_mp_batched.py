@@ -35,6 +35,8 @@ CASES = [
     (5000, 7, 128, 30, 17, 2),       # blocks cover only part of the rows
     (3000, 4, 64, 50, 8, 5),         # more blocks than rows: trailing blocks hold no rows
     (9000, 130, 64, None, 40, 8),    # wide theta, odd tail columns
+    (4096, 200, 64, None, 64, 4),    # K*d too large for the LDS copy of Theta: correction kernel reads it from global memory
+    (2048, 1, 64, None, 3, 2),       # a single column
 ]
 
 
