@@ -61,30 +61,44 @@ __device__ __forceinline__ void batched_f32_pass(const float *__restrict__ rbase
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-  // software pipeline: the loads of batch b+1 are issued before the MFMAs of batch b
+  // Software pipeline over batches of KU k-steps with two register buffers and
+  // no copies between them: the loads of batch b+1 are issued, then the MFMAs
+  // of batch b run, and only then is batch b+1 waited for -- a full batch of
+  // matrix work (KU*4*NB MFMAs of 64 cycles) covers the HBM latency.  (With a
+  // single "next" buffer copied into the "current" one the compiler hoists the
+  // copies, and their waits, up between the MFMAs of the current batch.)
   int j0 = 0;
   const int nfull = d / (2 * KU);
-  V4 a[KU], an[KU];
-  if (nfull > 0) {
+  V4 bufA[KU], bufB[KU];
+  auto load_batch = [&](V4 (&buf)[KU], int jb) {
 #pragma unroll
-    for (int u = 0; u < KU; u++) an[u] = load16<float, true>(rbase + (int64_t)(2 * u + kk) * col_stride);
-  }
-  for (int bt = 0; bt < nfull; bt++, j0 += 2 * KU) {
-#pragma unroll
-    for (int u = 0; u < KU; u++) a[u] = an[u];
-    if (!(EXP & 2) && bt + 1 < nfull) {
-#pragma unroll
-      for (int u = 0; u < KU; u++)
-        an[u] = load16<float, true>(rbase + (int64_t)(j0 + 2 * KU + 2 * u + kk) * col_stride);
-    }
+    for (int u = 0; u < KU; u++) buf[u] = load16<float, true>(rbase + (int64_t)(jb + 2 * u + kk) * col_stride);
+  };
+  auto mfma_batch = [&](const V4 (&buf)[KU], int jb) {
 #pragma unroll
     for (int u = 0; u < KU; u++) {
-      const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + ((j0 + 2 * u + kk) * 32 + arow) * 2);
+      const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + ((jb + 2 * u + kk) * 32 + arow) * 2);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u][m], b[n], acc[m][n], 0, 0, 0);
     }
+  };
+  if (nfull > 0) load_batch(bufA, 0);
+  int bt = 0;
+  for (; bt + 1 < nfull; bt += 2, j0 += 4 * KU) {
+    if (!(EXP & 2)) load_batch(bufB, j0 + 2 * KU);
+    __builtin_amdgcn_sched_barrier(0); // keep the loads ahead of the MFMAs: the scheduler sinks them otherwise
+    mfma_batch(bufA, j0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(EXP & 2) && bt + 2 < nfull) load_batch(bufA, j0 + 4 * KU);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(bufB, j0 + 2 * KU);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (bt < nfull) { // odd number of batches: the last one sits in bufA
+    mfma_batch(bufA, j0);
+    j0 += 2 * KU;
   }
   for (; j0 < d; j0 += 2) { // leftover k-steps; a column >= d contributes zeros
     const int col = j0 + kk;
