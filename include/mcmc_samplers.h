@@ -23,6 +23,18 @@
 extern "C" {
 #endif
 
+/* ---- the CPU path's entry points: src/mcmc_cpu/mcmc_cpu.h ----------------
+ * Same signatures; the chain is the same (draws, decisions, samples), the
+ * likelihood of every iteration runs on the MI355X (samplers/mcmc_cpu.c). */
+void cpu_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata, out_str *res); /* :12 */
+void tune_ess_cpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond, int length); /* :22 */
+void tune_target_a_cpu_v2(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond,
+                          double ratio, int max_reps);                                       /* :23 */
+void tune_target_a_cpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond); /* :24 */
+double acceptance_ratio(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, double lhood);  /* :32 */
+double log_prior(double *sample, mcmc_str mcin);                                            /* :33 */
+double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res);          /* :34 */
+
 /* ---- double precision: src/mcmc_gpu/mcmc_gpu.h -------------------------- */
 void gpu_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata, gpu_v_str gpu,
                  out_str *res);                                                             /* :16 */

@@ -1,0 +1,98 @@
+/*
+ * mcmc_cpu.c -- the entry points of the reference's mcmc_cpu
+ * (src/mcmc_cpu/mcmc_cpu.h:12-34) with their signatures, evaluated on the
+ * MI355X: a caller of cpu_sampler / tune_*_cpu / log_likelihood (cpu_host.c,
+ * tests/multiple_runs_cpu.c, tests/compare_cpu_gpu.c, tests/large_data_cpu.c)
+ * links against this library unchanged and gets the same chain -- same RNG
+ * draws, same accept / reject decisions (tests/test_gpu_samplers.py) -- with
+ * the likelihood of every iteration computed by the HIP kernels instead of
+ * cblas_dgemv + the serial libm loop (mcmc_cpu.c:419-445).
+ *
+ * These are the DP GPU functions under the CPU path's names: mcmc_gpu.cu is
+ * the same loop with a gpu_v_str argument added, and that argument is ignored
+ * here (mcmc_gpu.c).  There is no CPU arithmetic in this file; the CPU
+ * restatement of mcmc_cpu.c that the tests check against lives in oracle/.
+ */
+#include "mh_core.h"
+
+#include <string.h>
+
+static gpu_v_str no_gpu_args(void)
+{
+  gpu_v_str g;
+  memset(&g, 0, sizeof g);
+  return g;
+}
+
+/* mcmc_cpu.c:12-38 */
+void cpu_sampler(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str mct, mcmc_v_str mcdata, out_str *res)
+{
+  gpu_sampler(data, r, mcin, mct, mcdata, no_gpu_args(), res);
+  res->cpuTime = res->gpuTime; /* per-likelihood time in ms, the field cpu_host.c prints (mcmc_cpu.c:443) */
+}
+
+/* mcmc_cpu.c:125-210 */
+void tune_ess_cpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond, int length)
+{
+  tune_ess_gpu(data, r, mcin, mct, no_gpu_args(), initCond, length);
+}
+
+/* mcmc_cpu.c:212-272 */
+void tune_target_a_cpu_v2(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond, double ratio,
+                          int max_reps)
+{
+  tune_target_a_gpu_v2(data, r, mcin, mct, no_gpu_args(), initCond, ratio, max_reps);
+}
+
+/* mcmc_cpu.c:274-324: the legacy stepper with its fixed 5000-sample trial chains */
+void tune_target_a_cpu(data_str data, gsl_rng *r, mcmc_str mcin, mcmc_tune_str *mct, double *initCond)
+{
+  tune_target_a_gpu(data, r, mcin, mct, no_gpu_args(), initCond, 5000);
+}
+
+/* mcmc_cpu.c:397-417 */
+double acceptance_ratio(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, double lhood)
+{
+  return acceptance_ratio_gpu(mclocv, mcloc, mcin, lhood);
+}
+
+double log_prior(double *sample, mcmc_str mcin) { return log_prior_gpu(sample, mcin); }
+
+/* mcmc_cpu.c:419-445.  The reference reads data.data from host memory on every
+ * call; here the matrix has to be in HBM.  An attached context of the right
+ * shape is used as is; otherwise the matrix behind data.data is uploaded on
+ * the first call and kept until a call arrives with a different pointer or
+ * shape (the caller must not change the matrix in place between calls). */
+double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res)
+{
+  static mhlik_ctx *cached = NULL;
+  static const double *cached_ptr = NULL;
+  static int cached_n = 0, cached_d = 0;
+  int owned = 0;
+  mhlik_ctx *lik = NULL;
+  mhlik_ctx *att = mcmc_amd_attached_context();
+  mhlik_info info;
+  if (att && mhlik_get_info(att, &info) == MHLIK_OK && info.n_rows == (int64_t)mcin.Nd && info.n_cols == mcin.ddata &&
+      (info.precision & MHLIK_F64)) {
+    lik = att;
+  } else {
+    if (cached && (cached_ptr != data.data || cached_n != mcin.Nd || cached_d != mcin.ddata)) {
+      mhlik_destroy(cached);
+      cached = NULL;
+    }
+    if (!cached) {
+      mcmc_amd_attach_context(NULL);
+      cached = mh_acquire(data, mcin, MHLIK_F64, &owned);
+      mcmc_amd_attach_context(att);
+      cached_ptr = data.data;
+      cached_n = mcin.Nd;
+      cached_d = mcin.ddata;
+    }
+    lik = cached;
+  }
+  out_str tmp;
+  memset(&tmp, 0, sizeof tmp);
+  const double L = gpu_likelihood_d(lik, mcin, sample, res ? res : &tmp);
+  if (res) res->cpuTime = res->gpuTime;
+  return L;
+}

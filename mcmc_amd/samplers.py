@@ -72,7 +72,9 @@ EXPORTED_SYMBOLS = [
     "calculate_normalised_sample_means", "calculate_normalised_sample_means_sp", "init_rng", "init_rng_seed",
     "free_rng", "metropolis_gpu", "burn_in_metropolis_gpu", "gpu_likelihood_d", "gpu_likelihood_f",
     "mcmc_amd_attach_context", "mcmc_amd_attached_context", "mcmc_amd_trace_begin", "mcmc_amd_trace_end",
-    "mcmc_amd_set_verbose", "mcmc_amd_multichain_sampler",
+    "mcmc_amd_set_verbose", "mcmc_amd_multichain_sampler", "mcmc_amd_mp_multichain_sampler",
+    "cpu_sampler", "tune_ess_cpu", "tune_target_a_cpu_v2", "tune_target_a_cpu", "acceptance_ratio", "log_prior",
+    "log_likelihood",
 ]
 
 
@@ -253,6 +255,40 @@ def tune_target_a_gpu_v2(X, seed, burnin, rwsd, ratio=0.25, max_reps=40, rng=Non
     rng = rng or Rng(seed)
     S.tune_target_a_gpu_v2(data, rng.r, mcin, C.byref(mct), gpu_v_str(), _ptr(init), ratio, max_reps)
     return mct.rwsd
+
+
+def cpu_sampler(X, seed, Ns, burnin, rwsd, theta0=None, trace=True):
+    """cpu_sampler (mcmc_cpu.h:12) of the product library: the CPU path's entry
+    point, evaluated on the GPU."""
+    S = load_samplers()
+    X = np.asfortranarray(X, dtype=np.float64)
+    N, d = X.shape
+    samples = np.zeros((Ns, d))
+    burn = np.zeros((max(burnin, 1), d))
+    if theta0 is not None:
+        burn[0, :] = theta0
+    mcin = mcmc_str(ddata=d, Nd=N, Ns=Ns, burnin=burnin, impl=IMPL_CPU)
+    mct = mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
+    mcdata = mcmc_v_str(samples=_ptr(samples).value, burn=_ptr(burn).value)
+    res = out_str()
+    rng = Rng(seed)
+    S.cpu_sampler.argtypes = [data_str, C.c_void_p, mcmc_str, mcmc_tune_str, mcmc_v_str, C.POINTER(out_str)]
+    call = lambda: S.cpu_sampler(data_str(data=_ptr(X).value), rng.r, mcin, mct, mcdata, C.byref(res))
+    tr = _run_traced(S, call, Ns + burnin + 8) if trace else (call(), None)[1]
+    return dict(samples=samples, burn=burn, acceptance=res.acceptance, trace=tr, res=res)
+
+
+def log_likelihood(X, theta):
+    """log_likelihood (mcmc_cpu.h:34) of the product library."""
+    S = load_samplers()
+    X = np.asfortranarray(X, dtype=np.float64)
+    N, d = X.shape
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    S.log_likelihood.restype = C.c_double
+    S.log_likelihood.argtypes = [C.c_void_p, data_str, mcmc_str, C.POINTER(out_str)]
+    res = out_str()
+    return S.log_likelihood(_ptr(th), data_str(data=_ptr(X).value), mcmc_str(ddata=d, Nd=N, Ns=1, burnin=0, impl=IMPL_CPU),
+                            C.byref(res))
 
 
 def tune_ess_gpu(X, seed, burnin, rwsd, length, rng=None):

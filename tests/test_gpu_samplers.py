@@ -150,3 +150,25 @@ def test_config1_shape_repeated_runs_share_one_stream():
                               O.mcmc_v_str(samples=O.ptr(samples).value, burn=O.ptr(burn).value), C.byref(res))
                 assert np.array_equal(samples, g["samples"]), run
                 assert res.acceptance == g["acceptance"]
+
+
+def test_cpu_path_entry_points_run_on_the_gpu_and_match_the_oracle():
+    """cpu_sampler / log_likelihood of the product library (the reference's
+    mcmc_cpu.h names) against the oracle's CPU restatement of the same names."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 30_000, 5
+    X = synthetic_host(12345, N, d)
+    ref = O.cpu_sampler(X, 4, 120, 30, 0.03)
+    run = S.cpu_sampler(X, 4, 120, 30, 0.03)
+    assert np.array_equal(ref["trace"]["accept"], run["trace"]["accept"])
+    assert np.array_equal(ref["samples"], run["samples"])
+    assert np.array_equal(ref["burn"], run["burn"])
+    rng = np.random.default_rng(0)
+    for X2 in (X, synthetic_host(7, 5000, 3)):  # a second matrix: the cached context must be replaced
+        for _ in range(2):
+            th = rng.normal(0, 0.2, X2.shape[1])
+            want, _ = O.log_likelihood(X2, th)
+            got = S.log_likelihood(X2, th)
+            assert abs(got - want) <= 1e-10 * abs(want)
