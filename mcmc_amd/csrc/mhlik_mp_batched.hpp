@@ -172,18 +172,24 @@ __device__ __forceinline__ double wave_total(double v)
 // One row of a (block, chain) pair that needs double precision: exactly the
 // per-row arithmetic of mp_tile_kernel / oracle/mp_path.c.  Kept out of line:
 // four inlined copies of exp + three logs cost more registers than the call.
-__device__ __noinline__ void mpb_pair_terms(float af, double ad, double eps, bool bright, double &s_rs, double &s_lb)
+struct MpbTerms {
+  double rs, lb; // this row's log B - log L, and log(L - B) (0 unless bright)
+};
+__device__ __noinline__ MpbTerms mpb_pair_terms(float af, double ad, double eps, bool bright)
 {
   const float sig_s = mhlik_sigmoidf_det(af);
   const double Bd = (double)sig_s - eps; // mcmc_mp.cu:63,146
   const double L = 1.0 / (1.0 + exp(ad));
+  MpbTerms t;
   if (bright) {
     const float Bf = (float)Bd;
-    s_rs += (double)logf(Bf) - log(L);
-    s_lb += log(L - (double)Bf);
+    t.rs = (double)logf(Bf) - log(L);
+    t.lb = log(L - (double)Bf);
   } else {
-    s_rs += log(Bd) - log(L);
+    t.rs = log(Bd) - log(L);
+    t.lb = 0.0;
   }
+  return t;
 }
 
 // The rows of data block b against the theta of G chains c[0..G): per chain
@@ -270,7 +276,12 @@ __device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, cons
     }
     if (row < covered) {
 #pragma unroll
-      for (int q = 0; q < G; q++) mpb_pair_terms(af[q], ad[q], p.eps, (bright_mask >> c[q]) & 1ull, s_rs[q], s_lb[q]);
+      for (int q = 0; q < G; q++) {
+        const bool br = (bright_mask >> c[q]) & 1ull;
+        const MpbTerms t = mpb_pair_terms(af[q], ad[q], p.eps, br);
+        s_rs[q] += t.rs;
+        if (br) s_lb[q] += t.lb; // a dark pair's sum stays +0.0 exactly as before
+      }
     }
   }
 #pragma unroll
