@@ -117,3 +117,28 @@ def test_many_tiles_uses_wide_segment_sum():
         b = lk.loglik(th)
     assert a == b
     assert abs(a - want) <= REL_TOL_DP * abs(want)
+
+
+def test_empty_matrix_and_wide_theta():
+    """N = 0: the sum over no rows is 0 (mcmc_cpu.c:438-441 starts from 0);
+    d > 256: theta no longer fits the kernarg segment and goes through the
+    pinned staging buffer."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    with Likelihood(0, 4, precision=3) as lk:
+        lk.upload(np.zeros((0, 4), order="F"))
+        lk.upload(np.zeros((0, 4), order="F", dtype=np.float32))
+        assert lk.loglik(np.ones(4)) == 0.0
+        assert lk.loglik_f32(np.ones(4, dtype=np.float32)) == 0.0
+        assert list(lk.loglik_batched(np.ones((3, 4)))) == [0.0, 0.0, 0.0]
+    N, d = 3000, 300
+    X = synthetic_host(11, N, d)
+    th = np.random.default_rng(4).normal(0, 0.05, d)
+    want, mvout = O.log_likelihood(X, th)
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        got = lk.loglik(th)
+        dots = lk.rowdots(th)
+    assert np.array_equal(dots, mvout)
+    assert abs(got - want) <= REL_TOL_DP * abs(want)
