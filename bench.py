@@ -71,50 +71,38 @@ def main():
     N, d = a.rows, a.cols
     lk = Likelihood(N, d, precision=F64, device=local_rank, rank=rank, world=world, timing=True)
     lk.fill_synthetic(a.data_seed)
+    in_library_rccl = True
     if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        lk.comm_init(bytes(idt.cpu().numpy().tobytes()))
-
-    lib = S.load_samplers()
-    P = C.c_void_p
-    lib.burn_in_metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P]
-    lib.metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P,
-                                   C.POINTER(C.c_int), C.POINTER(S.out_str)]
+        # the in-library path: ncclAllReduce on the context's stream, inside the device-resident chain
+        failed = 0
+        try:
+            if os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
+                raise RuntimeError("fallback forced")
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            lk.comm_init(bytes(idt.cpu().numpy().tobytes()))
+        except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+            print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+            failed = 1
+        t = torch.tensor([failed], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        in_library_rccl = int(t.item()) == 0
+    elif os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
+        in_library_rccl = False
 
     K, W = a.steps, a.warmup
-    burn_len = max(W, 1)  # burn-in does 1 + (burnin-1) = W likelihood evaluations
-    samples = np.zeros((K, d))
-    burn = np.zeros((burn_len, d))
-    mcin = S.mcmc_str(ddata=d, Nd=N, Ns=K, burnin=burn_len, impl=S.IMPL_GPU)
     rwsd = 2.38 / np.sqrt(d) * 2e-3  # small random-walk step: the posterior at N=1e7 is narrow
-    mct = S.mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
-    mcdata = S.mcmc_v_str(samples=samples.ctypes.data, burn=burn.ctypes.data)
-    prop, cur = np.zeros(d), np.zeros(d)
-    mclocv = S.mcmc_int_v(proposed=prop.ctypes.data, current=cur.ctypes.data)
-    mcloc = S.mcmc_int()
-    res = S.out_str()
-    accepted = C.c_int(0)
-    rng = S.Rng(a.seed)  # same seed on every rank: identical proposals and decisions everywhere
-    trace = np.zeros(K + burn_len + 8, dtype=S.TRACE_DTYPE)
-
-    # warm-up: W untimed iterations (burn-in loop of the sampler)
-    lib.burn_in_metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc))
-    lib.mcmc_amd_trace_begin(trace.ctypes.data_as(P), len(trace))
-    barrier()
-    t0 = time.perf_counter()
-    lib.metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc), C.byref(accepted), C.byref(res))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ntrace = lib.mcmc_amd_trace_end()
+    if in_library_rccl:
+        elapsed, kernel_ms, n_accepted = run_c_sampler(a, lk, S, np, N, d, K, W, rwsd, barrier)
+    else:
+        elapsed, kernel_ms, n_accepted = run_host_loop(a, lk, S, np, torch, dist, dev, world, d, K, W, rwsd, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(res.kernelTime)  # mean device time of the streaming kernel over the K timed steps (HIP events)
     info = lk.info()
     local_bytes = info["local_rows"] * d * 8
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -135,14 +123,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": "Bayesian logistic regression MH, N=%d d=%d DP (%s)" % (N, d, workload_name(N, d)),
                    "rows": N, "cols": d, "rows_per_gpu": info["local_rows"],
-                   "parallelism": "rows sharded over %d GPU(s), per-iteration RCCL all-reduce" % world
+                   "parallelism": ("rows sharded over %d GPU(s), per-iteration RCCL all-reduce%s" %
+                                   (world, "" if in_library_rccl else " through torch.distributed (fallback host loop)"))
                    if world > 1 else "single GPU"},
         "likelihood_GBps_whole_job": N * d * 8 / (elapsed / K) / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "lik_tile_kernel<double>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": local_bytes},
-        "acceptance": accepted.value / K,
+        "acceptance": n_accepted / K,
     }
 
     # ---- side measurements on rank 0 of a single-GPU run ----------------------------------
@@ -156,6 +145,91 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_c_sampler(a, lk, S, np, N, d, K, W, rwsd, barrier):
+    """W burn-in iterations, then K timed iterations of metropolis_gpu (the C
+    sampler loop, device-resident chain).  Returns (seconds, mean kernel ms, accepted)."""
+    lib = S.load_samplers()
+    P = C.c_void_p
+    lib.burn_in_metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P]
+    lib.metropolis_gpu.argtypes = [P, P, S.mcmc_str, S.mcmc_tune_str, S.mcmc_v_str, S.mcmc_int_v, P,
+                                   C.POINTER(C.c_int), C.POINTER(S.out_str)]
+    burn_len = max(W, 1)  # burn-in does 1 + (burnin-1) = W likelihood evaluations
+    samples = np.zeros((K, d))
+    burn = np.zeros((burn_len, d))
+    mcin = S.mcmc_str(ddata=d, Nd=N, Ns=K, burnin=burn_len, impl=S.IMPL_GPU)
+    mct = S.mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
+    mcdata = S.mcmc_v_str(samples=samples.ctypes.data, burn=burn.ctypes.data)
+    prop, cur = np.zeros(d), np.zeros(d)
+    mclocv = S.mcmc_int_v(proposed=prop.ctypes.data, current=cur.ctypes.data)
+    mcloc = S.mcmc_int()
+    res = S.out_str()
+    accepted = C.c_int(0)
+    rng = S.Rng(a.seed)  # same seed on every rank: identical proposals and decisions everywhere
+    lib.burn_in_metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc))
+    barrier()
+    t0 = time.perf_counter()
+    lib.metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc), C.byref(accepted), C.byref(res))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, float(res.kernelTime), accepted.value
+
+
+def run_host_loop(a, lk, S, np, torch, dist, dev, world, d, K, W, rwsd, barrier):
+    """Fallback when the in-library RCCL communicator cannot be set up: the same
+    MH iteration (d ziggurat draws, likelihood, prior N(0,10^2), uniform, accept
+    iff log u <= ratio) driven from Python, the per-segment sums all-reduced by
+    torch.distributed (backend nccl = RCCL) and added in segment order."""
+    lib = S.load_samplers()
+    lib.gsl_ran_gaussian_ziggurat.restype = C.c_double
+    lib.gsl_ran_gaussian_ziggurat.argtypes = [C.c_void_p, C.c_double]
+    lib.gsl_rng_uniform.restype = C.c_double
+    lib.gsl_rng_uniform.argtypes = [C.c_void_p]
+    rng = S.Rng(a.seed)
+    slots = torch.zeros(lk.segments, dtype=torch.float64, device=dev)
+
+    def likelihood(theta):
+        v = lk.loglik(theta)
+        if world == 1:
+            return v
+        slots.copy_(torch.from_numpy(lk.segment_sums()))
+        dist.all_reduce(slots, op=dist.ReduceOp.SUM)
+        total = 0.0
+        for x in slots.cpu().numpy():
+            total += float(x)
+        return total
+
+    def log_prior(theta):
+        return float(np.sum(np.log(np.exp(-(theta / 10.0) ** 2 / 2.0) / (np.sqrt(2.0 * np.pi) * 10.0))))
+
+    cur = np.zeros(d)
+    cpost = log_prior(cur) + likelihood(cur)
+    acc = [0]
+    ms = []
+
+    def step(count):
+        nonlocal cur, cpost
+        prop = cur + np.array([lib.gsl_ran_gaussian_ziggurat(rng.r, rwsd) for _ in range(d)])
+        L = likelihood(prop)
+        ms.append(lk.last_kernel()[0])
+        ppost = log_prior(prop) + L
+        u = lib.gsl_rng_uniform(rng.r)
+        if np.log(u) <= ppost - cpost:
+            cur, cpost = prop, ppost
+            if count:
+                acc[0] += 1
+
+    for _ in range(max(W - 1, 0)):
+        step(False)
+    ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, float(np.mean(ms)) if ms else 0.0, acc[0]
 
 
 def workload_name(N, d):
