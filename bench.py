@@ -36,11 +36,79 @@ def parse():
     ap.add_argument("--data-seed", type=int, default=12345)
     ap.add_argument("--cpu-iters", type=int, default=60, help="MH iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the SP / multi-core side measurements")
+    ap.add_argument("--workload", default="mh", choices=["mh", "batched_f32", "batched_f64", "mp_batched"],
+                    help="mh (default): BASELINE's metric, the DP MH step at N=10M d=64.  The others time BASELINE "
+                         "configs[4] (64 lock-step chains, X.Theta on MFMA, N=10M d=128) on one GPU")
+    ap.add_argument("--chains", type=int, default=64)
+    ap.add_argument("--resamp-factor", type=int, default=16, help="mp_batched: 1/F of the dark blocks re-examined per step")
     return ap.parse_args()
+
+
+MFMA_PEAK_TFLOPS = {"batched_f32": 157.3, "batched_f64": 78.6, "mp_batched": 157.3}  # dense, MI355X_MICROARCH.md
+
+
+def main_batched(a):
+    """BASELINE configs[4]: one step = one lock-step iteration of K chains (host
+    proposals, one batched likelihood pass, host accept tests), the C loop of
+    samplers/multichain.c.  Roofline: the X.Theta pass on the matrix cores."""
+    import numpy as np
+    import torch
+
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or a.gpus != 1:
+        raise SystemExit("--workload %s runs on one GPU" % a.workload)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
+    from mcmc_amd import Likelihood
+    from mcmc_amd import samplers as S
+
+    N = a.rows
+    d = a.cols if a.cols != 64 else 128  # the configuration's d unless --cols says otherwise
+    K, steps, W = a.chains, a.steps, max(a.warmup, 2)
+    rwsd = 2.38 / np.sqrt(d) * 2e-3
+    seeds = list(range(a.seed, a.seed + K))
+    prec = {"batched_f32": 2, "batched_f64": 1, "mp_batched": 3}[a.workload]
+    with Likelihood(N, d, precision=prec, segments=1 if a.workload == "mp_batched" else 0, timing=True) as lk:
+        lk.fill_synthetic(a.data_seed)
+
+        def run(n, burn):
+            if a.workload == "mp_batched":
+                return S.mp_multichain_sampler(lk, seeds, n, burn, rwsd, 64, N // 64, a.resamp_factor, 1.7e-7,
+                                               shared_phase=True, theta0=np.zeros(d))
+            return S.multichain_sampler(lk, seeds, n, burn, rwsd, use_f32=a.workload == "batched_f32")
+
+        run(W, 2)  # warm-up (mp: the all-bright first evaluations happen here)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(steps, 0 if a.workload != "mp_batched" else 2)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        evals = steps + (2 if a.workload == "mp_batched" else 0)
+        kernel_ms, _ = lk.last_kernel()  # device time of the last step's likelihood kernels (HIP events)
+    flops = 2.0 * N * d * K
+    achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[a.workload]
+    line = {
+        "metric": "chain_iterations_per_sec", "value": K * evals / elapsed, "unit": "chain-it/s", "n_gpus": 1,
+        "steps": steps, "warmup": W, "ms_per_step": elapsed / evals * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": {"batched_f32": "f32", "batched_f64": "f64", "mp_batched": "f32+f64"}[a.workload],
+        "data": "synthetic",
+        "config": {"workload": "%d lock-step MH chains, N=%d d=%d, %s (BASELINE configs[4])" % (K, N, d, a.workload),
+                   "rows": N, "cols": d, "chains": K,
+                   "resamp_factor": a.resamp_factor if a.workload == "mp_batched" else None},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel_ms": kernel_ms,
+                     "kernel": {"batched_f32": "lik_batched_f32_kernel", "batched_f64": "lik_batched_f64_kernel",
+                                "mp_batched": "mpb_dark_kernel + mpb_fix_kernel + mpb_final_kernel (flops of the float pass)"}[a.workload],
+                     "algorithmic_flops_per_launch": flops},
+        "acceptance": float(np.mean(out["accepted"])) / steps,
+    }
+    print(json.dumps(line), flush=True)
 
 
 def main():
     a = parse()
+    if a.workload != "mh":
+        return main_batched(a)
     import numpy as np
     import torch
     import torch.distributed as dist

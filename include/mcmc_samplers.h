@@ -107,10 +107,12 @@ void mcmc_amd_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mcmc_str mc
  * re-examined blocks).  Chain k is mp_sampler run with generator r[k].
  * samples [K][Ns][d]; burn [K][burnin][d]; accepted [K]; bright_blocks [K] or
  * NULL.  shared_phase != 0: all chains re-examine the phase chain 0 drew (same
- * random streams, 1/ResampFactor of the double matrix read per iteration). */
+ * random streams, 1/ResampFactor of the double matrix read per iteration).
+ * theta0: d values every chain starts from, or NULL for the reference's
+ * theta = 1 (mcmc_mp.cu:433). */
 void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *mpVar, mcmc_str mcin,
                                     mcmc_tune_str mct, double *samples, double *burn, int *accepted,
-                                    double lhoodBound, int shared_phase, int *bright_blocks);
+                                    double lhoodBound, int shared_phase, int *bright_blocks, const double *theta0);
 
 /* By default every sampler / tuner call uploads data.data (or data.dataf) to
  * a fresh context and frees it on return, as the reference does

@@ -154,10 +154,12 @@ static void mpk_eval(mpk_env *e, gsl_rng **r, const double *Theta)
 /* samples [K][Ns][d]; burn [K][burnin][d] (row 0 of a chain is not written,
  * like mp_sampler); accepted [K]; bright_blocks [K] (may be NULL): bright
  * blocks of each chain after the last iteration.  The context must hold both
- * matrices with segments = 1. */
+ * matrices with segments = 1.  theta0 (d values, may be NULL): common start of
+ * the chains instead of the reference's theta = 1, which saturates the
+ * sigmoids (and makes log(sigma_S - eps) NaN) once d is large. */
 void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *mpVar, mcmc_str mcin,
                                     mcmc_tune_str mct, double *samples, double *burn, int *accepted,
-                                    double lhoodBound, int shared_phase, int *bright_blocks)
+                                    double lhoodBound, int shared_phase, int *bright_blocks, const double *theta0)
 {
   const int d = mcin.ddata;
   if (K < 1 || K > MHLIK_MAX_BATCH) {
@@ -192,7 +194,7 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
   const long bl = mcin.burnin > 0 ? mcin.burnin : 1;
   const long total = (mcin.burnin > 0 ? mcin.burnin - 1 : 0) + mcin.Ns;
   if (mcin.burnin != 0) { /* start of burn_in_metropolis_mp, :430-440 */
-    for (long i = 0; i < (long)K * d; i++) cur[i] = 1;
+    for (long i = 0; i < (long)K * d; i++) cur[i] = theta0 ? theta0[i % d] : 1; /* :433 starts every chain at 1 */
     mpk_eval(&e, r, cur);
     for (int k = 0; k < K; k++) cpost[k] = mh_log_prior_d(cur + (long)k * d, d, MP_PRIOR_SD) + e.L[k];
   }

@@ -322,7 +322,8 @@ def multichain_sampler(lik, seeds, Ns, burnin, rwsd, use_f32=False):
     return dict(samples=samples, burn=burn, accepted=acc)
 
 
-def mp_multichain_sampler(lik, seeds, Ns, burnin, rwsd, block_rows, blocks, resamp_factor, bound, shared_phase=False):
+def mp_multichain_sampler(lik, seeds, Ns, burnin, rwsd, block_rows, blocks, resamp_factor, bound, shared_phase=False,
+                          theta0=None):
     """K lock-step mixed-precision chains on an existing Likelihood context
     (both matrices, segments=1); chain k is mp_sampler with generator seeds[k]."""
     S = load_samplers()
@@ -337,10 +338,11 @@ def mp_multichain_sampler(lik, seeds, Ns, burnin, rwsd, block_rows, blocks, resa
     mp = mp_str(dataBlocks=blocks, dataBlockSz=block_rows, ResampFactor=resamp_factor)
     S.mcmc_amd_mp_multichain_sampler.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(mp_str), mcmc_str,
                                                  mcmc_tune_str, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
-                                                 C.c_int, C.c_void_p]
+                                                 C.c_int, C.c_void_p, C.c_void_p]
+    th0 = None if theta0 is None else np.ascontiguousarray(theta0, dtype=np.float64)
     S.mcmc_amd_mp_multichain_sampler(lik.handle, K, arr, C.byref(mp), mcin, mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd),
                                      _ptr(samples), _ptr(burn), _ptr(acc), float(bound), int(shared_phase),
-                                     _ptr(bright))
+                                     _ptr(bright), None if th0 is None else _ptr(th0))
     return dict(samples=samples, burn=burn, accepted=acc, bright=bright, mp=mp)
 
 
