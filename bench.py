@@ -122,14 +122,23 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
+    # rehearsal knobs for a one-GPU box: every rank on one device, torch.distributed over gloo (the in-library RCCL
+    # communicator cannot be built then -- RCCL refuses two ranks on one GPU -- so the fallback loop runs)
+    backend = os.environ.get("MHLIK_BENCH_BACKEND", "nccl")
+    if "MHLIK_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MHLIK_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of torch collectives live
 
     from mcmc_amd import Likelihood, F64, F32
     from mcmc_amd import samplers as S
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -146,7 +155,7 @@ def main():
         try:
             if os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
                 raise RuntimeError("fallback forced")
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            idt = torch.zeros(128, dtype=torch.uint8, device=red_dev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
@@ -154,7 +163,7 @@ def main():
         except Exception as e:  # noqa: BLE001 -- reported below, on every rank
             print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
             failed = 1
-        t = torch.tensor([failed], dtype=torch.int32, device=dev)
+        t = torch.tensor([failed], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         in_library_rccl = int(t.item()) == 0
     elif os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
@@ -165,9 +174,9 @@ def main():
     if in_library_rccl:
         elapsed, kernel_ms, n_accepted = run_c_sampler(a, lk, S, np, N, d, K, W, rwsd, barrier)
     else:
-        elapsed, kernel_ms, n_accepted = run_host_loop(a, lk, S, np, torch, dist, dev, world, d, K, W, rwsd, barrier)
+        elapsed, kernel_ms, n_accepted = run_host_loop(a, lk, S, np, torch, dist, red_dev, world, d, K, W, rwsd, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
