@@ -48,12 +48,14 @@ __device__ __forceinline__ float neg_log1pexp_fast(float x)
 }
 
 // One 128-row pass of a wave: acc[m][n] = rows {row0 + 4i + m} x chains of
-// N-block n, accumulated over all d columns.  rbase = tile + row0 + 4*arow.
+// N-block n, accumulated over all d columns.  ubase = tile + row0 (wave-uniform): a load's address is a
+// scalar base (column of the k-step) plus one 32-bit per-lane byte offset, not a 64-bit VGPR pair per load.
 template <int NB, int KU, int EXP>
-__device__ __forceinline__ void batched_f32_pass(const float *__restrict__ rbase, int64_t col_stride, int d,
+__device__ __forceinline__ void batched_f32_pass(const float *__restrict__ ubase, int64_t col_stride, int d,
                                                  const float *thetaL, int arow, int kk, f32x16 (&acc)[4][NB])
 {
   typedef Vec16<float>::type V4;
+  const unsigned loff = (unsigned)((4 * arow + kk * col_stride) * sizeof(float)); // lane's rows, lane's column of the k-step
 #pragma unroll
   for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -72,7 +74,9 @@ __device__ __forceinline__ void batched_f32_pass(const float *__restrict__ rbase
   V4 bufA[KU], bufB[KU];
   auto load_batch = [&](V4 (&buf)[KU], int jb) {
 #pragma unroll
-    for (int u = 0; u < KU; u++) buf[u] = load16<float, true>(rbase + (int64_t)(jb + 2 * u + kk) * col_stride);
+    for (int u = 0; u < KU; u++)
+      buf[u] = load16<float, true>(reinterpret_cast<const float *>(
+          reinterpret_cast<const char *>(ubase + (int64_t)(jb + 2 * u) * col_stride) + loff));
   };
   auto mfma_batch = [&](const V4 (&buf)[KU], int jb) {
 #pragma unroll
@@ -103,7 +107,9 @@ __device__ __forceinline__ void batched_f32_pass(const float *__restrict__ rbase
   for (; j0 < d; j0 += 2) { // leftover k-steps; a column >= d contributes zeros
     const int col = j0 + kk;
     V4 a1 = {0.f, 0.f, 0.f, 0.f};
-    if (col < d) a1 = load16<float, true>(rbase + (int64_t)col * col_stride);
+    if (col < d)
+      a1 = load16<float, true>(reinterpret_cast<const float *>(
+          reinterpret_cast<const char *>(ubase + (int64_t)j0 * col_stride) + loff));
     const f32x2 b = *reinterpret_cast<const f32x2 *>(thetaL + (col * 32 + arow) * 2);
 #pragma unroll
     for (int m = 0; m < 4; m++)
@@ -152,9 +158,8 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
     const int row0 = wave * 256 + pass * 128; // first tile row of this pass
-    const float *rbase = tbase + row0 + 4 * arow;
     f32x16 acc[4][NB];
-    batched_f32_pass<NB, KU, EXP>(rbase, g.col_stride, d, thetaL, arow, kk, acc);
+    batched_f32_pass<NB, KU, EXP>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
 
     // epilogue: accumulator (m, n, r) of lane l is tile row  row0 + 4*i + m  with
     // i = (r&3) + 8*(r>>2) + 4*(l>>5), chain n*32 + (l&31)

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <vector>
 #include "batched_lab_v2.hpp"
+#include "batched_lab_v3.hpp"
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -87,6 +88,17 @@ int main(int argc, char **argv)
         printf("f32 %-28s %.3f ms  %.1f TF   max rel diff vs v1 per tile %.2e\n", label, ms, flops / ms / 1e9, worst); \
         CK(hipFree(th2)); }
       RUNV2X(4, 32, "v2 glds KU=4")
+#define RUNV3(HINTV, label) if (d == 128) { auto k = lik_batched3_f32_kernel<8, HINTV>; \
+        CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
+        std::vector<double> h3((size_t)ntiles * 64); \
+        CK(hipMemcpy(h3.data(), P, sizeof(double) * ntiles * 64, hipMemcpyDeviceToHost)); \
+        double worst = 0; \
+        for (size_t i = 0; i < h3.size(); i++) { double e = fabs(h1[i] - h3[i]) / fabs(h1[i]); if (e > worst) worst = e; } \
+        printf("f32 %-28s %.3f ms  %.1f TF   max rel diff vs v1 per tile %.2e\n", label, ms, flops / ms / 1e9, worst); }
+      RUNV3(0, "v3 interleaved epilogue")
+      RUNV3(1, "v3 same + sched groups")
+      RUN32(0, "current (again)")
       CK(hipFree(P2));
     }
     CK(hipFree(X)); CK(hipFree(tv)); CK(hipFree(th)); CK(hipFree(P));
