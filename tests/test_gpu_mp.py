@@ -78,3 +78,17 @@ def test_mp_sampler_runs():
     out = S.mp_sampler(X, 1, 200, 50, 0.05, block_rows=64, blocks=N // 64, resamp_factor=2, bound=1.7e-7)
     assert np.isfinite(out["samples"]).all()
     assert out["mp"].brightBlocks + out["mp"].darkBlocks == N // 64
+
+
+def test_deterministic_float_sigmoid_is_bit_identical_on_host_and_device():
+    """The mixed-precision path takes log(sigma_D - (sigma_S - eps)): the float
+    sigmoid must be the same function in the oracle (host) and in the kernels
+    (gfx950).  tools/check_detmath compares 2^20 arguments bit for bit."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_detmath")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "exp mismatches 0, sigmoid mismatches 0" in out.stdout, out.stdout
