@@ -172,3 +172,55 @@ def test_mt_variant_matches_serial():
     want, _ = O.log_likelihood(X, th)
     got = L.oracle_log_likelihood_mt(O.ptr(th), O.ptr(X), 50000, 8, 50000, 4)
     assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_golden_mp_and_chain_statistics():
+    """The oracle's mixed-precision and autocorrelation / ESS restatements
+    against tests/golden/oracle_golden_mp_ess.json (made by
+    tests/golden/make_golden_mp_ess.py): they are the checkers of the GPU tests."""
+    import ctypes as C
+    import json
+
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(sys_path, "oracle_golden_mp_ess.json")))
+    L = O.lib()
+    L.oracle_set_verbose(0)
+    L.oracle_mp_likelihood.restype = C.c_double
+    L.oracle_mp_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    fh = float.fromhex
+    for s in g["mp_sequences"]:
+        X = synthetic_host(s["data_seed"], s["N"], s["d"])
+        Xf = np.asfortranarray(X.astype(np.float32))
+        z = np.ones(s["blocks"], dtype=np.int8)
+        for call, (th, want, wb) in enumerate(zip(s["theta"], s["value"], s["bright_after"])):
+            th = np.array([fh(v) for v in th])
+            nb, nd = C.c_int(), C.c_int()
+            v = L.oracle_mp_likelihood(O.ptr(X), O.ptr(Xf), s["N"], s["d"], s["N"], O.ptr(th), s["block_rows"],
+                                       s["blocks"], s["resamp_factor"], call % s["resamp_factor"], s["u_seed"], call,
+                                       fh(s["eps"]), O.ptr(z), C.byref(nb), C.byref(nd))
+            assert nb.value == wb and nb.value + nd.value == s["blocks"]
+            assert abs(v - fh(want)) <= 1e-12 * abs(fh(want))
+        assert int(z.sum()) == s["z_final_sum"]
+    a = g["autocorrelation"]
+    rng = np.random.default_rng(a["seed"])
+    x = np.zeros((a["n"], a["d"]))
+    e = rng.normal(size=(a["n"], a["d"]))
+    for i in range(1, a["n"]):
+        x[i] = a["rho"] * x[i - 1] + e[i]
+    ac = np.zeros(a["lags"])
+    tot = L.circular_autocorrelation(O.ptr(ac), O.ptr(x), a["d"], a["n"], a["lags"])
+    want = np.array([fh(v) for v in a["out_v"]])
+    assert np.allclose(ac, want, rtol=1e-12, atol=0)
+    assert abs(tot - fh(a["sum"])) <= 1e-12 * abs(fh(a["sum"]))
+    t = g["tune_ess"]
+    X = synthetic_host(t["data_seed"], t["N"], t["d"])
+    mct = O.mcmc_tune_str(rwsd=t["rwsd_in"], rwsdf=t["rwsd_in"])
+    r = O.Rng(t["chain_seed"], L)
+    mvout = np.empty(t["N"])
+    init = np.zeros(t["d"])
+    L.tune_ess_cpu(O.data_str(data=O.ptr(X).value, mvout=O.ptr(mvout).value), r.r,
+                   O.mcmc_str(ddata=t["d"], Nd=t["N"], Ns=1, burnin=t["burnin"], impl=0), C.byref(mct), O.ptr(init),
+                   t["length"])
+    assert mct.rwsd == fh(t["rwsd_out"])
