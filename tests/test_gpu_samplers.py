@@ -34,6 +34,25 @@ def test_gpu_sampler_trace_equals_cpu_sampler(N, d, seed):
     assert margin > 1e-9
 
 
+@pytest.mark.parametrize("Ns,burnin", [(1, 1), (1, 2), (2, 1), (5000, 1)])
+def test_gpu_sampler_shortest_and_chunked_chains(Ns, burnin):
+    """Chain lengths at the edges: one sample after a burn-in that is only the initial evaluation
+    (burn loop i = 1 .. burnin-1 is empty, mcmc_gpu.cu:563-600), and a chain longer than one device batch
+    (4096 iterations per upload)."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(12345, 2000, 3)
+    rwsd = 2.38 / np.sqrt(3) * 0.2
+    ref = O.cpu_sampler(X, 3, Ns, burnin, rwsd)
+    got = S.gpu_sampler(X, 3, Ns, burnin, rwsd)
+    assert len(ref["trace"]) == len(got["trace"]) == Ns + burnin - 1
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"])
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert np.array_equal(ref["burn"], got["burn"])
+    assert ref["acceptance"] == got["acceptance"]
+
+
 def test_tuner_matches_oracle():
     import ctypes as C
 
