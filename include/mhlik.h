@@ -133,6 +133,18 @@ int mhlik_loglik_f32(mhlik_ctx *ctx, const float *theta, float *out);
 int mhlik_loglik_batched_f64(mhlik_ctx *ctx, const double *Theta, int32_t K, double *out);
 int mhlik_loglik_batched_f32(mhlik_ctx *ctx, const float *Theta, int32_t K, double *out);
 
+/* How mhlik_loglik_batched_f32 forms the float dots x_i.theta_k (no counterpart in the reference):
+ *   MHLIK_BATCHED_F32_EXACT  f32 MFMA: bit-for-bit the column-ordered fmaf chain of mhlik_loglik_f32's kernel;
+ *                            bound by the f32 matrix rate.
+ *   MHLIK_BATCHED_F32_SPLIT  (default) every float is split exactly into three bfloat16 pieces and the six
+ *                            leading piece products run on the 16x faster bf16 MFMA; the dropped products are
+ *                            below 2^-23 of |x.theta|, i.e. the dots are as close to the exact dot as the fmaf
+ *                            chain's, but not the same bits.
+ * The default can also be chosen with the environment variable MHLIK_BATCHED_F32=exact|split. */
+#define MHLIK_BATCHED_F32_EXACT 0
+#define MHLIK_BATCHED_F32_SPLIT 1
+int mhlik_set_batched_f32_mode(mhlik_ctx *ctx, int32_t mode);
+
 /* Per-row dot products x_i.theta of this shard's rows, to a host array of
  * local-row-count doubles: the reference's data.mvout / d.cuLhood
  * (mcmc_cpu.c:436, mcmc_gpu.cu:233).  Test / debug entry point. */

@@ -18,6 +18,7 @@
 
 #include "mhlik_kernels.hpp"
 #include "mhlik_batched.hpp"
+#include "mhlik_batched_x3.hpp"
 #include "mhlik_mp.hpp"
 #include "mhlik_mp_batched.hpp"
 #include "mhlik_chain.hpp"
@@ -148,6 +149,7 @@ struct mhlik_ctx {
   size_t theta_cap = 0;
   double *rowdots = nullptr;
   size_t rowdots_cap = 0;
+  int batched_f32_mode = MHLIK_BATCHED_F32_SPLIT; // mhlik_set_batched_f32_mode
 
   // mixed precision
   int8_t *mp_z = nullptr;
@@ -660,6 +662,8 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
   hipDeviceProp_t prop;
   CREATE_CHK(hipGetDeviceProperties(&prop, dev));
   c->compute_units = prop.multiProcessorCount;
+  if (const char *e = getenv("MHLIK_BATCHED_F32")) // "exact" | "split": default of mhlik_set_batched_f32_mode
+    c->batched_f32_mode = strcmp(e, "exact") == 0 ? MHLIK_BATCHED_F32_EXACT : MHLIK_BATCHED_F32_SPLIT;
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&c->ev0));
   CREATE_CHK(hipEventCreate(&c->ev1));

@@ -39,6 +39,7 @@
 #pragma once
 
 #include "mhlik_batched.hpp"
+#include "mhlik_batched_x3.hpp"
 #include "mhlik_mp.hpp"
 
 namespace mhlik {
@@ -159,6 +160,88 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_kernel(const float *__rest
     const int chain = n * 32 + c;
     if (chain < p.K) partials[(int64_t)chain * pstride + tile] = s;
   }
+}
+
+// The same pass with the float dots formed from three bfloat16 pieces (mhlik_batched_x3.hpp; chosen by
+// mhlik_set_batched_f32_mode, like the plain K-chain float pass).  Only DARK rows take their value from this pass,
+// and a dark row's term is a float sum in the reference too; everything that decides an indicator or enters
+// log(L - B) is recomputed by mpb_fix_kernel in the single-chain kernel's exact order either way, so the indicators
+// do not depend on the mode.  Persistent workgroups (grid = what fits the chip), a wave's pass is 64 rows = one
+// 64-row group of one data block.  Accumulator (m, n, r) of lane l: tile row row0 + 4*(4*(l>>4) + r) + m,
+// chain 16n + (l&15).  z: [block][64 chains]; partials[chain*pstride + tile].
+template <int NB>
+__global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__restrict__ X, TileGeom g,
+                                                                const u32x4 *__restrict__ theta_dev, int d_pad,
+                                                                MpbParams p, const int8_t *__restrict__ z,
+                                                                double *__restrict__ partials, int64_t pstride,
+                                                                int64_t ntiles)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4 *thetaL = reinterpret_cast<u32x4 *>(smem);
+  const int theta_vecs = d_pad / kX3KBlock * NB * 3 * 64;
+  double *red = reinterpret_cast<double *>(smem + (size_t)theta_vecs * sizeof(u32x4)); // [4 waves][NB][64 lanes]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < theta_vecs; i += kBlock) thetaL[i] = theta_dev[i];
+  __syncthreads();
+
+  const int grp = lane >> 4, ccol = lane & 15;
+  const int64_t all = (int64_t)p.blocks << p.block_shift;
+  const int64_t covered = all < p.n_rows ? all : p.n_rows; // rows that belong to a considered block
+  const float epsf = (float)p.eps;
+  double sum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; n++) sum[n] = 0.0;
+
+  auto epi = [&](int64_t tile, int row0, const f32x4 (&acc)[4][NB]) {
+    const int64_t g0 = tile * kMpTileRows + row0; // global row of the pass's first row
+    const int64_t left = covered - g0;
+    if (left <= 0) return; // wave-uniform
+    const int lim = left >= 64 ? 64 : (int)left;
+    const int64_t blk = g0 >> p.block_shift;
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+      const int8_t zc = z[blk * kBatchCols + n * 16 + ccol];
+      float s = 0.f;
+      if (lim == 64) { // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) s += mpb_dark_term(acc[m][n][r], epsf);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const float t = mpb_dark_term(acc[m][n][r], epsf);
+            s += (4 * (4 * grp + r) + m < lim) ? t : 0.f;
+          }
+      }
+      sum[n] += zc == 0 ? (double)s : 0.0;
+    }
+  };
+  auto tile_done = [&](int64_t tile) {
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+      red[(wave * NB + n) * 64 + lane] = sum[n];
+      sum[n] = 0.0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NB * 16) {
+      const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) s += red[(w * NB + n) * 64 + c + 16 * q];
+      const int chain = n * 16 + c;
+      if (chain < p.K) partials[(int64_t)chain * pstride + tile] = s;
+    }
+    __syncthreads();
+  };
+  batched_x3_stream<NB, 6, 0>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave, g.col_stride, g.d,
+                              d_pad, thetaL, lane, epi, tile_done);
 }
 
 __device__ __forceinline__ double wave_total(double v)

@@ -121,6 +121,13 @@ class Likelihood:
         self._chk(fn(self._ctx, _ptr(Th), Th.shape[0], _ptr(out)))
         return out
 
+    def set_batched_f32_mode(self, mode):
+        """'exact' (f32 MFMA, the single-theta kernel's fmaf chain) or 'split' (three bfloat16 pieces, default)."""
+        self.set_batched_f32_mode_raw({"exact": 0, "split": 1}[mode])
+
+    def set_batched_f32_mode_raw(self, mode):
+        self._chk(self._lib.mhlik_set_batched_f32_mode(self._ctx, int(mode)))
+
     def rowdots(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)
         out = np.empty(self.local_rows, dtype=np.float64)

@@ -29,9 +29,10 @@ def test_batched_f64_matches_oracle(N, d, K):
     assert np.all(np.abs(got[:4] - single) <= 1e-10 * np.abs(single))
 
 
+@pytest.mark.parametrize("mode", ["exact", "split"])
 @pytest.mark.parametrize("N,d,K", [(4096, 8, 64), (10000, 3, 5), (5000, 16, 33), (3000, 128, 64), (1025, 7, 1),
-                                   (20000, 64, 16), (70001, 11, 48)])
-def test_batched_f32_within_sp_tolerance(N, d, K):
+                                   (20000, 64, 16), (70001, 11, 48), (2500, 33, 17), (1500, 1, 2), (300000, 32, 64)])
+def test_batched_f32_within_sp_tolerance(N, d, K, mode):
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
 
@@ -41,11 +42,57 @@ def test_batched_f32_within_sp_tolerance(N, d, K):
     want = _oracle_batched(X, Theta)
     with Likelihood(N, d, precision=2) as lk:
         lk.upload(Xf)
+        lk.set_batched_f32_mode(mode)
         got = lk.loglik_batched(Theta.astype(np.float32), dtype=np.float32)
         single = np.array([lk.loglik_f32(th.astype(np.float32)) for th in Theta[:4]])
     assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want)), (np.abs(got - want) / np.abs(want)).max()
     # same float row dots as the single-theta kernel; only the exp/log flavour differs
     assert np.all(np.abs(got[:4] - single) <= 2e-6 * np.abs(single))
+
+
+def test_batched_f32_split_is_as_close_to_the_double_dots_as_the_fmaf_chain():
+    """The split-bf16 pass (mhlik_batched_x3.hpp) against the f32-MFMA pass: both take the same float matrix and
+    float Theta; the yardstick is the double evaluation of those float inputs.  The split pass may not be further
+    from it than the float chain's own rounding allows (a few float ulps of the per-row magnitude, averaged over
+    the rows), and the two passes agree with each other to that level."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, K = 50000, 96, 64
+    Xf = np.asfortranarray(synthetic_host(777, N, d).astype(np.float32))
+    Thf = np.random.default_rng(9).normal(0, 0.2, (K, d)).astype(np.float32)
+    dots = Xf.astype(np.float64) @ Thf.astype(np.float64).T
+    want = -np.logaddexp(0.0, dots).sum(axis=0)
+    with Likelihood(N, d, precision=2) as lk:
+        lk.upload(Xf)
+        lk.set_batched_f32_mode("exact")
+        exact = lk.loglik_batched(Thf, dtype=np.float32)
+        lk.set_batched_f32_mode("split")
+        split = lk.loglik_batched(Thf, dtype=np.float32)
+        again = lk.loglik_batched(Thf, dtype=np.float32)
+    assert np.array_equal(split, again)  # fixed summation order: reproducible run to run
+    err_exact = np.abs(exact - want) / np.abs(want)
+    err_split = np.abs(split - want) / np.abs(want)
+    assert err_exact.max() <= 1e-6 and err_split.max() <= 1e-6, (err_exact.max(), err_split.max())
+    assert err_split.max() <= 4 * max(err_exact.max(), 5e-8), (err_exact.max(), err_split.max())
+
+
+def test_batched_f32_split_falls_back_when_theta_is_too_wide_for_lds():
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, K = 2048, 500, 64  # three-piece image of Theta: 16 k-blocks x 48 KB > 160 KB
+    X = synthetic_host(5, N, d)
+    Thf = np.random.default_rng(1).normal(0, 0.05, (K, d)).astype(np.float32)
+    with Likelihood(N, d, precision=2) as lk:
+        lk.upload(np.asfortranarray(X.astype(np.float32)))
+        lk.set_batched_f32_mode("split")
+        a = lk.loglik_batched(Thf, dtype=np.float32)
+        lk.set_batched_f32_mode("exact")
+        b = lk.loglik_batched(Thf, dtype=np.float32)
+        with pytest.raises(Exception):
+            lk.set_batched_f32_mode_raw(7)
+    assert np.array_equal(a, b)
 
 
 def test_batched_overflow_column():

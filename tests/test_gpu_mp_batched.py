@@ -40,8 +40,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["exact", "split"])  # float dots of the dark pass: f32 MFMA / three bf16 pieces
 @pytest.mark.parametrize("N,d,block_rows,blocks,K,rf", CASES)
-def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, K, rf):
+def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, K, rf, mode):
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
 
@@ -56,6 +57,7 @@ def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, 
         lk.upload(X)
         lk.upload(Xf)
         lk.mp_reset_batched(block_rows, blocks, K)
+        lk.set_batched_f32_mode(mode)
         for call in range(5):
             Th = rng.normal(0, 0.5 / np.sqrt(d), (K, d))
             choose = rng.integers(0, rf, K).astype(np.int32)
@@ -114,7 +116,8 @@ def test_mp_batched_rejects_bad_arguments():
             lk.mp_loglik_batched(np.zeros((4, d)), 2, [0, 1, 2, 0], [1, 2, 3, 4], 0, 1e-7)
 
 
-def test_mp_multichain_sampler_reproduces_mp_sampler_per_chain():
+@pytest.mark.parametrize("mode", ["exact", "split"])
+def test_mp_multichain_sampler_reproduces_mp_sampler_per_chain(mode):
     """Chain k of the lock-step sampler walks the chain mp_sampler walks with
     the same generator seed: same proposals, same accept decisions, same
     samples (the dark float sums agree to ~1e-7 relative, far inside the
@@ -130,6 +133,7 @@ def test_mp_multichain_sampler_reproduces_mp_sampler_per_chain():
     with Likelihood(N, d, precision=3, segments=1) as lk:
         lk.upload(X)
         lk.upload(Xf)
+        lk.set_batched_f32_mode(mode)
         out = S.mp_multichain_sampler(lk, seeds, Ns, burnin, 0.05, 64, N // 64, 4, 1.7e-7)
     assert np.isfinite(out["samples"]).all()
     assert np.array_equal(out["samples"][0], out["samples"][2])  # same seed, same chain
