@@ -83,10 +83,10 @@ def main_batched(a):
         run(W, 2)  # warm-up (mp: the all-bright first evaluations happen here)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = run(steps, 0 if a.workload != "mp_batched" else 2)
+        out = run(steps, 2)  # chain start + one burn-in iteration + `steps` sampling iterations
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        evals = steps + (2 if a.workload == "mp_batched" else 0)
+        evals = steps + 2
         kernel_ms, _ = lk.last_kernel()  # device time of the last step's likelihood kernels (HIP events)
     flops = 2.0 * N * d * K
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0

@@ -133,6 +133,15 @@ int mhlik_loglik_f32(mhlik_ctx *ctx, const float *theta, float *out);
 int mhlik_loglik_batched_f64(mhlik_ctx *ctx, const double *Theta, int32_t K, double *out);
 int mhlik_loglik_batched_f32(mhlik_ctx *ctx, const float *Theta, int32_t K, double *out);
 
+/* The same evaluation in two halves, for a caller that has host work to do while the device runs (the K-chain
+ * samplers draw the next iteration's random numbers meanwhile; no counterpart in the reference, whose likelihood
+ * call blocks, mcmc_gpu.cu:107).  _begin stages Theta and queues the kernels; _end waits and writes the K results.
+ * Between the two the context accepts no other evaluation (MHLIK_ESTATE), and Theta may be reused at once (it has
+ * been copied). */
+int mhlik_loglik_batched_begin_f64(mhlik_ctx *ctx, const double *Theta, int32_t K);
+int mhlik_loglik_batched_begin_f32(mhlik_ctx *ctx, const float *Theta, int32_t K);
+int mhlik_loglik_batched_end(mhlik_ctx *ctx, double *out);
+
 /* How mhlik_loglik_batched_f32 forms the float dots x_i.theta_k (no counterpart in the reference):
  *   MHLIK_BATCHED_F32_EXACT  f32 MFMA: bit-for-bit the column-ordered fmaf chain of mhlik_loglik_f32's kernel;
  *                            bound by the f32 matrix rate.
@@ -205,6 +214,11 @@ int mhlik_mp_reset_batched(mhlik_ctx *ctx, int32_t block_rows, int32_t blocks, i
  * (host [K], may be NULL) are the counts after resampling. */
 int mhlik_mp_loglik_batched(mhlik_ctx *ctx, const mhlik_mp_batch *st, const double *Theta, double *out,
                             int32_t *bright_blocks, int32_t *dark_blocks);
+
+/* The same evaluation in two halves (see mhlik_loglik_batched_begin_f64): _begin copies st and Theta and queues
+ * the kernels, _end waits and writes the results.  No other evaluation on the context in between. */
+int mhlik_mp_loglik_batched_begin(mhlik_ctx *ctx, const mhlik_mp_batch *st, const double *Theta);
+int mhlik_mp_loglik_batched_end(mhlik_ctx *ctx, double *out, int32_t *bright_blocks, int32_t *dark_blocks);
 
 /* Copy the indicators to the host as [K][blocks] (tests / diagnostics). */
 int mhlik_mp_indicators_batched(mhlik_ctx *ctx, int8_t *z);

@@ -111,6 +111,9 @@ _SIGS = [
     ("mhlik_loglik_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     ("mhlik_loglik_batched_f64", C.c_int, [_P, _P, C.c_int32, _P]),
     ("mhlik_loglik_batched_f32", C.c_int, [_P, _P, C.c_int32, _P]),
+    ("mhlik_loglik_batched_begin_f64", C.c_int, [_P, _P, C.c_int32]),
+    ("mhlik_loglik_batched_begin_f32", C.c_int, [_P, _P, C.c_int32]),
+    ("mhlik_loglik_batched_end", C.c_int, [_P, _P]),
     ("mhlik_set_batched_f32_mode", C.c_int, [_P, C.c_int32]),
     ("mhlik_rowdots_f64", C.c_int, [_P, _P, _P]),
     ("mhlik_mp_reset", C.c_int, [_P, C.c_int32, C.c_int32]),
@@ -118,6 +121,8 @@ _SIGS = [
     ("mhlik_mp_bound", C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("mhlik_mp_reset_batched", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     ("mhlik_mp_loglik_batched", C.c_int, [_P, C.POINTER(MpBatch), _P, _P, _P, _P]),
+    ("mhlik_mp_loglik_batched_begin", C.c_int, [_P, C.POINTER(MpBatch), _P]),
+    ("mhlik_mp_loglik_batched_end", C.c_int, [_P, _P, _P, _P]),
     ("mhlik_mp_indicators_batched", C.c_int, [_P, _P]),
     ("mhlik_chain_begin_f64", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
     ("mhlik_chain_begin_f32", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_float)]),

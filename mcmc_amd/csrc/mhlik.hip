@@ -150,6 +150,11 @@ struct mhlik_ctx {
   double *rowdots = nullptr;
   size_t rowdots_cap = 0;
   int batched_f32_mode = MHLIK_BATCHED_F32_SPLIT; // mhlik_set_batched_f32_mode
+  // an evaluation begun with mhlik_*_begin and not yet collected with the matching _end
+  int pending_kind = 0; // 0 none, 1 batched, 2 mixed-precision batched
+  int pending_nvec = 0;
+  unsigned long long pending_seq = 0;
+  bool pending_published = false;
 
   // mixed precision
   int8_t *mp_z = nullptr;
@@ -428,7 +433,7 @@ int wait_published(mhlik_ctx *c, unsigned long long seq)
 
 // Add the per-segment sums of `nvec` results (tile partials -> segment slots
 // -> all shards -> host), leaving out[k] = sum over segments in index order.
-int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
+int combine_launch(mhlik_ctx *c, const Store &s, int nvec)
 {
   const int nseg = c->nseg, nloc = (int)c->segs.size();
   const bool dist = c->comm != nullptr;
@@ -461,8 +466,18 @@ int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
     published = true;
   }
   HIPCHK(c, hipGetLastError());
-  if (published) {
-    int rc = wait_published(c, seq);
+  c->pending_nvec = nvec;
+  c->pending_seq = seq;
+  c->pending_published = published;
+  return MHLIK_OK;
+}
+
+// Second half: wait for what combine_launch queued and add the slots on the host.
+int combine_wait(mhlik_ctx *c, double *out)
+{
+  const int nseg = c->nseg, nvec = c->pending_nvec;
+  if (c->pending_published) {
+    int rc = wait_published(c, c->pending_seq);
     if (rc) return rc;
   } else {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -481,10 +496,25 @@ int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
   return MHLIK_OK;
 }
 
+int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
+{
+  int rc = combine_launch(c, s, nvec);
+  return rc ? rc : combine_wait(c, out);
+}
+
+// Evaluation entry points refuse to start while a begun evaluation has not been collected: they share the
+// context's staging buffers, partials and completion word.
+#define NOT_PENDING(c)                                                                                              \
+  do {                                                                                                              \
+    if ((c)->pending_kind)                                                                                          \
+      return fail((c), MHLIK_ESTATE, "an evaluation begun with mhlik_*_begin is pending: collect it with its _end call first"); \
+  } while (0)
+
 template <typename T> int loglik_impl(mhlik_ctx *c, const T *theta, double *out, T *rowdots_dev)
 {
   if (!c) return MHLIK_EINVAL;
   if (!theta || !out) return fail(c, MHLIK_EINVAL, "theta and out must not be NULL");
+  NOT_PENDING(c);
   Store &s = store_of<T>(c);
   if (!s.has_data)
     return fail(c, MHLIK_ESTATE, "no %s design matrix on the device: upload or fill first",

@@ -104,7 +104,11 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
   V4 x[8], y[8];
   auto load_block = [&](V4 (&buf)[8], int64_t tile, int pass, int kb) {
     const float *ubase = X + tile * tile_stride + pass * 256 + wave * 64;
-    if (kb < nfull) { // scalar column base + the lane's 32-bit byte offset
+    if (EXP & 8) { // lab: the same bytes as 1 KB-contiguous wave loads (column (pass*nkb + kb)*8 + u, rows 256*wave + 4*lane)
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        buf[u] = load16<float, true>(X + tile * tile_stride + (int64_t)((pass * nkb + kb) * 8 + u) * col_stride + 256 * wave + 4 * lane);
+    } else if (kb < nfull) { // scalar column base + the lane's 32-bit byte offset
 #pragma unroll
       for (int u = 0; u < 8; u++)
         buf[u] = load16<float, true>(reinterpret_cast<const float *>(
@@ -270,6 +274,47 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_x3_kernel(const float *
   };
   batched_x3_stream<NB, TERMS, EXP>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave, g.col_stride,
                                     g.d, d_pad, thetaL, lane, epi, tile_done);
+}
+
+// piece t (0, 1, 2) of v as a truncated bfloat16: the top 16 bits of v, of v - piece 0, of v - piece 0 - piece 1
+__device__ __forceinline__ unsigned x3_piece(float v, int t)
+{
+  for (int s = 0; s < t; s++) v = x3_residual(v);
+  return __float_as_uint(v) >> 16;
+}
+
+// The LDS image of Theta for the split kernels, built on the device from the caller's row-major Theta
+// (raw[chain*d + j], float or double: a double is rounded to float first, as the single-chain kernels do):
+//   out[(((kb*NB + n)*3 + t)*64 + lane)*4 + i] = piece_t(Theta[kb*32 + 8g + 2i][16n + c]) | piece_t(Theta[.. + 1][..]) << 16
+// with c = lane & 15, g = lane >> 4; zero outside d columns / K chains.  Grid-stride over the dwords.
+template <typename TIn>
+__device__ __forceinline__ void x3_theta_image(const TIn *__restrict__ raw, int d, int K, int d_pad, int NB,
+                                               unsigned *__restrict__ out, int64_t first, int64_t step)
+{
+  const int64_t total = (int64_t)d_pad / kX3KBlock * NB * 3 * 64 * 4;
+  for (int64_t o = first; o < total; o += step) {
+    const int i = (int)(o & 3), lane = (int)((o >> 2) & 63);
+    int64_t rest = o >> 8;
+    const int t = (int)(rest % 3);
+    rest /= 3;
+    const int n = (int)(rest % NB), kb = (int)(rest / NB);
+    const int c = lane & 15, g = lane >> 4, chain = n * 16 + c;
+    unsigned w = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int j = kb * kX3KBlock + 8 * g + 2 * i + e;
+      const float v = (j < d && chain < K) ? (float)raw[(int64_t)chain * d + j] : 0.f;
+      w |= x3_piece(v, t) << (16 * e);
+    }
+    out[o] = w;
+  }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void x3_theta_image_kernel(const TIn *__restrict__ raw, int d, int K, int d_pad,
+                                                                int NB, unsigned *__restrict__ out)
+{
+  x3_theta_image(raw, d, K, d_pad, NB, out, (int64_t)blockIdx.x * kBlock + threadIdx.x, (int64_t)gridDim.x * kBlock);
 }
 
 } // namespace mhlik

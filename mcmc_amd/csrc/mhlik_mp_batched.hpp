@@ -244,6 +244,34 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__r
                               d_pad, thetaL, lane, epi, tile_done);
 }
 
+// Theta three ways, on the device, from the caller's row-major double Theta (raw[chain*d + j]):
+//   pd / pf  [K][d_fix] doubles / floats, zero padded: the scalar loads of mpb_fix_kernel ((float)theta[j] as the
+//            single-chain kernel rounds it);
+//   image    the float Theta of the dark pass: the three-piece image of mhlik_batched_x3.hpp (split != 0), else the
+//            B-operand order of the f32 MFMA pass, [column j][chain-in-block 32][block 2], d_pad columns.
+__global__ __launch_bounds__(kBlock) void mpb_theta_prep_kernel(const double *__restrict__ raw, int d, int K, int d_fix,
+                                                                double *__restrict__ pd, float *__restrict__ pf,
+                                                                int split, int d_pad, int NB3, void *__restrict__ image)
+{
+  const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x, step = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = first; i < (int64_t)K * d_fix; i += step) {
+    const int k = (int)(i / d_fix), j = (int)(i % d_fix);
+    const double v = j < d ? raw[(int64_t)k * d + j] : 0.0;
+    pd[i] = v;
+    pf[i] = (float)v;
+  }
+  if (split) {
+    x3_theta_image(raw, d, K, d_pad, NB3, reinterpret_cast<unsigned *>(image), first, step);
+  } else {
+    float *img = reinterpret_cast<float *>(image);
+    for (int64_t o = first; o < (int64_t)d_pad * kBatchCols; o += step) {
+      const int n = (int)(o & 1), cc = (int)((o >> 1) & 31), j = (int)(o >> 6);
+      const int chain = n * 32 + cc;
+      img[o] = (j < d && chain < K) ? (float)raw[(int64_t)chain * d + j] : 0.f;
+    }
+  }
+}
+
 __device__ __forceinline__ double wave_total(double v)
 {
   v = wave_sum_lane63(v);

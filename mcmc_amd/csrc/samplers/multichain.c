@@ -24,34 +24,30 @@ typedef struct {
   double *prop, *cur; /* [K][d] */
   float *propf;       /* [K][d] when f32 */
   double *cpost, *L;  /* [K] */
+  double *inc, *u;    /* [K][d], [K]: the random numbers of the NEXT iteration, drawn while the device runs this one */
 } mc_state;
 
-static void mc_eval(mc_state *s, const double *Theta)
+static void mc_begin(mc_state *s, const double *Theta)
 {
   if (s->f32) {
     for (long i = 0; i < (long)s->K * s->d; i++) s->propf[i] = (float)Theta[i];
-    MH_CHECK(mhlik_loglik_batched_f32(s->lik, s->propf, s->K, s->L), s->lik);
+    MH_CHECK(mhlik_loglik_batched_begin_f32(s->lik, s->propf, s->K), s->lik);
   } else {
-    MH_CHECK(mhlik_loglik_batched_f64(s->lik, Theta, s->K, s->L), s->lik);
+    MH_CHECK(mhlik_loglik_batched_begin_f64(s->lik, Theta, s->K), s->lik);
   }
 }
 
-/* one lock-step iteration; returns nothing, bumps accepted[k] when asked */
-static void mc_step(mc_state *s, gsl_rng **r, double sd, int *accepted)
+static void mc_end(mc_state *s) { MH_CHECK(mhlik_loglik_batched_end(s->lik, s->L), s->lik); }
+
+/* What one iteration takes from chain k's generator, in the reference's order: d Gaussians, then the uniform of
+ * the accept test (mcmc_gpu.cu:105,111).  Neither depends on the chain's state and nothing else draws from r[k]
+ * in between, so they can be drawn ahead of the evaluation they belong to without changing the stream. */
+static void mc_draw(mc_state *s, gsl_rng **r, double sd)
 {
   const int K = s->K, d = s->d;
-  for (int k = 0; k < K; k++)
-    for (int j = 0; j < d; j++) s->prop[(long)k * d + j] = s->cur[(long)k * d + j] + gsl_ran_gaussian_ziggurat(r[k], sd);
-  mc_eval(s, s->prop);
   for (int k = 0; k < K; k++) {
-    const double ppost = mh_log_prior_d(s->prop + (long)k * d, d, PRIOR_SD) + s->L[k];
-    const double ratio = ppost - s->cpost[k];
-    const double u = gsl_rng_uniform(r[k]);
-    if (log(u) <= ratio) {
-      memcpy(s->cur + (long)k * d, s->prop + (long)k * d, sizeof(double) * d);
-      s->cpost[k] = ppost;
-      if (accepted) accepted[k] += 1;
-    }
+    for (int j = 0; j < d; j++) s->inc[(long)k * d + j] = gsl_ran_gaussian_ziggurat(r[k], sd);
+    s->u[k] = gsl_rng_uniform(r[k]);
   }
 }
 
@@ -75,30 +71,60 @@ void mcmc_amd_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mcmc_str mc
   s.propf = (float *)calloc((size_t)K * d, sizeof(float));
   s.cpost = (double *)calloc((size_t)K, sizeof(double));
   s.L = (double *)calloc((size_t)K, sizeof(double));
+  s.inc = (double *)calloc((size_t)K * d, sizeof(double));
+  s.u = (double *)calloc((size_t)K, sizeof(double));
+  double *u_now = (double *)calloc((size_t)K, sizeof(double));
+  double *pprior = (double *)calloc((size_t)K, sizeof(double));
 
   const long bl = mcin.burnin > 0 ? mcin.burnin : 1;
+  const long nburn = mcin.burnin > 0 ? mcin.burnin - 1 : 0; /* burn-in iterations after the start */
+  const long total = nburn + mcin.Ns;
   for (int k = 0; k < K; k++) {
     accepted[k] = 0;
     if (mcin.burnin > 0) memcpy(s.cur + (long)k * d, burn + (long)k * bl * d, sizeof(double) * d);
   }
-  if (mcin.burnin > 0) {
-    mc_eval(&s, s.cur);
+  if (mcin.burnin > 0) { /* the chain start, burn_in_metropolis_gpu (mcmc_gpu.cu:139-146) */
+    mc_begin(&s, s.cur);
+    if (total > 0) mc_draw(&s, r, mct.rwsd);
+    mc_end(&s);
     for (int k = 0; k < K; k++) s.cpost[k] = mh_log_prior_d(s.cur + (long)k * d, d, PRIOR_SD) + s.L[k];
-    for (int i = 1; i < mcin.burnin; i++) {
-      mc_step(&s, r, mct.rwsd, NULL);
-      for (int k = 0; k < K; k++) memcpy(burn + ((long)k * bl + i) * d, s.cur + (long)k * d, sizeof(double) * d);
-    }
+  } else if (total > 0) {
+    mc_draw(&s, r, mct.rwsd);
   }
-  for (int i = 0; i < mcin.Ns; i++) {
-    mc_step(&s, r, mct.rwsd, accepted);
-    for (int k = 0; k < K; k++)
-      memcpy(samples + ((long)k * mcin.Ns + i) * d, s.cur + (long)k * d, sizeof(double) * d);
+  for (long it = 0; it < total; it++) {
+    /* proposal from the numbers drawn ahead; this iteration's uniforms move aside before the next draw */
+    for (long i = 0; i < (long)K * d; i++) s.prop[i] = s.cur[i] + s.inc[i];
+    memcpy(u_now, s.u, sizeof(double) * K);
+    mc_begin(&s, s.prop);
+    /* host work that does not need the likelihood runs under the device pass: the next iteration's random
+     * numbers (never past the last iteration) and the proposals' log prior */
+    if (it + 1 < total) mc_draw(&s, r, mct.rwsd);
+    for (int k = 0; k < K; k++) pprior[k] = mh_log_prior_d(s.prop + (long)k * d, d, PRIOR_SD);
+    mc_end(&s);
+    const int sampling = it >= nburn;
+    for (int k = 0; k < K; k++) {
+      const double ppost = pprior[k] + s.L[k];
+      const double ratio = ppost - s.cpost[k];
+      if (log(u_now[k]) <= ratio) {
+        memcpy(s.cur + (long)k * d, s.prop + (long)k * d, sizeof(double) * d);
+        s.cpost[k] = ppost;
+        if (sampling) accepted[k] += 1;
+      }
+      if (sampling)
+        memcpy(samples + ((long)k * mcin.Ns + (it - nburn)) * d, s.cur + (long)k * d, sizeof(double) * d);
+      else
+        memcpy(burn + ((long)k * bl + it + 1) * d, s.cur + (long)k * d, sizeof(double) * d);
+    }
   }
   free(s.prop);
   free(s.cur);
   free(s.propf);
   free(s.cpost);
   free(s.L);
+  free(s.inc);
+  free(s.u);
+  free(u_now);
+  free(pprior);
 }
 
 /* ------------------------------------------------------------------------- *
@@ -134,11 +160,17 @@ typedef struct {
   double *L;
 } mpk_env;
 
-static void mpk_eval(mpk_env *e, gsl_rng **r, const double *Theta)
+/* the phases of one evaluation, from each chain's own generator (mcmc_mp.cu:504) */
+static void mpk_draw_phase(mpk_env *e, gsl_rng **r, int32_t *choose)
 {
-  for (int k = 0; k < e->K; k++) e->choose[k] = (int32_t)gsl_rng_uniform_int(r[k], (unsigned long)e->mp->ResampFactor);
+  for (int k = 0; k < e->K; k++) choose[k] = (int32_t)gsl_rng_uniform_int(r[k], (unsigned long)e->mp->ResampFactor);
   if (e->shared_phase)
-    for (int k = 1; k < e->K; k++) e->choose[k] = e->choose[0];
+    for (int k = 1; k < e->K; k++) choose[k] = choose[0];
+}
+
+/* queue one evaluation with the phases in e->choose; mpk_end collects it */
+static void mpk_begin(mpk_env *e, const double *Theta)
+{
   mhlik_mp_batch st;
   st.block_rows = e->mp->dataBlockSz;
   st.blocks = e->mp->dataBlocks;
@@ -148,8 +180,10 @@ static void mpk_eval(mpk_env *e, gsl_rng **r, const double *Theta)
   st.u_seed = e->seeds;
   st.u_call = e->calls++;
   st.bound_eps = e->bound;
-  MH_CHECK(mhlik_mp_loglik_batched(e->lik, &st, Theta, e->L, e->nb, e->nd), e->lik);
+  MH_CHECK(mhlik_mp_loglik_batched_begin(e->lik, &st, Theta), e->lik);
 }
+
+static void mpk_end(mpk_env *e) { MH_CHECK(mhlik_mp_loglik_batched_end(e->lik, e->L, e->nb, e->nd), e->lik); }
 
 /* samples [K][Ns][d]; burn [K][burnin][d] (row 0 of a chain is not written,
  * like mp_sampler); accepted [K]; bright_blocks [K] (may be NULL): bright
@@ -186,6 +220,14 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
   double *prop = (double *)calloc((size_t)K * d, sizeof(double));
   double *cur = (double *)calloc((size_t)K * d, sizeof(double));
   double *cpost = (double *)calloc((size_t)K, sizeof(double));
+  /* what the NEXT iteration takes from the generators, drawn while the device runs this one: per chain, in the
+   * reference's order, d Gaussians (:389), the phase (:504), the uniform of the accept test (:400).  None of them
+   * depends on the chain's state and nothing else draws from r[k] in between. */
+  double *inc = (double *)calloc((size_t)K * d, sizeof(double));
+  int32_t *choose_next = (int32_t *)calloc((size_t)K, sizeof(int32_t));
+  double *u_next = (double *)calloc((size_t)K, sizeof(double));
+  double *u_now = (double *)calloc((size_t)K, sizeof(double));
+  double *pprior = (double *)calloc((size_t)K, sizeof(double));
   for (int k = 0; k < K; k++) {
     e.seeds[k] = MP_U_SEED;
     accepted[k] = 0;
@@ -193,21 +235,37 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
 
   const long bl = mcin.burnin > 0 ? mcin.burnin : 1;
   const long total = (mcin.burnin > 0 ? mcin.burnin - 1 : 0) + mcin.Ns;
+#define MPK_DRAW_AHEAD()                                                                              \
+  do {                                                                                                \
+    for (int k = 0; k < K; k++)                                                                       \
+      for (int j = 0; j < d; j++) inc[(long)k * d + j] = gsl_ran_gaussian_ziggurat(r[k], mct.rwsd);   \
+    mpk_draw_phase(&e, r, choose_next);                                                               \
+    for (int k = 0; k < K; k++) u_next[k] = gsl_rng_uniform(r[k]);                                    \
+  } while (0)
   if (mcin.burnin != 0) { /* start of burn_in_metropolis_mp, :430-440 */
     for (long i = 0; i < (long)K * d; i++) cur[i] = theta0 ? theta0[i % d] : 1; /* :433 starts every chain at 1 */
-    mpk_eval(&e, r, cur);
+    mpk_draw_phase(&e, r, e.choose);
+    mpk_begin(&e, cur);
+    if (total > 0) MPK_DRAW_AHEAD();
+    mpk_end(&e);
     for (int k = 0; k < K; k++) cpost[k] = mh_log_prior_d(cur + (long)k * d, d, MP_PRIOR_SD) + e.L[k];
+  } else if (total > 0) {
+    MPK_DRAW_AHEAD();
   }
   for (long it = 0; it < total; it++) {
     const int sampling = mcin.burnin > 0 ? it >= mcin.burnin - 1 : 1;
-    for (int k = 0; k < K; k++)
-      for (int j = 0; j < d; j++) prop[(long)k * d + j] = cur[(long)k * d + j] + gsl_ran_gaussian_ziggurat(r[k], mct.rwsd);
-    mpk_eval(&e, r, prop);
+    for (long i = 0; i < (long)K * d; i++) prop[i] = cur[i] + inc[i];
+    memcpy(e.choose, choose_next, sizeof(int32_t) * K);
+    memcpy(u_now, u_next, sizeof(double) * K);
+    mpk_begin(&e, prop);
+    /* under the device pass: the next iteration's random numbers (never past the last iteration), the log prior */
+    if (it + 1 < total) MPK_DRAW_AHEAD();
+    for (int k = 0; k < K; k++) pprior[k] = mh_log_prior_d(prop + (long)k * d, d, MP_PRIOR_SD);
+    mpk_end(&e);
     for (int k = 0; k < K; k++) {
-      const double ppost = mh_log_prior_d(prop + (long)k * d, d, MP_PRIOR_SD) + e.L[k];
+      const double ppost = pprior[k] + e.L[k];
       const double a = exp(ppost - cpost[k]); /* acceptance_ratio_mp, :635 */
-      const double u = gsl_rng_uniform(r[k]);
-      if (u <= a) { /* :402 */
+      if (u_now[k] <= a) { /* :402 */
         memcpy(cur + (long)k * d, prop + (long)k * d, sizeof(double) * d);
         cpost[k] = ppost;
         if (sampling) accepted[k] += 1;
@@ -220,6 +278,7 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
       }
     }
   }
+#undef MPK_DRAW_AHEAD
   long nb_sum = 0;
   for (int k = 0; k < K; k++) {
     if (bright_blocks) bright_blocks[k] = e.nb[k];
@@ -237,4 +296,9 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
   free(prop);
   free(cur);
   free(cpost);
+  free(inc);
+  free(choose_next);
+  free(u_next);
+  free(u_now);
+  free(pprior);
 }

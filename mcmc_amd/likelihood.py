@@ -121,6 +121,20 @@ class Likelihood:
         self._chk(fn(self._ctx, _ptr(Th), Th.shape[0], _ptr(out)))
         return out
 
+    def loglik_batched_begin(self, Theta, dtype=np.float64):
+        """First half of loglik_batched: queue the evaluation and return; loglik_batched_end() collects it."""
+        Th = np.ascontiguousarray(Theta, dtype=dtype)
+        if Th.ndim != 2 or Th.shape[1] != self.n_cols:
+            raise ValueError("Theta must be [K, %d]" % self.n_cols)
+        fn = self._lib.mhlik_loglik_batched_begin_f64 if dtype == np.float64 else self._lib.mhlik_loglik_batched_begin_f32
+        self._chk(fn(self._ctx, _ptr(Th), Th.shape[0]))
+        self._begun = Th.shape[0]
+
+    def loglik_batched_end(self):
+        out = np.empty(getattr(self, "_begun", 0) or 1, dtype=np.float64)
+        self._chk(self._lib.mhlik_loglik_batched_end(self._ctx, _ptr(out)))
+        return out
+
     def set_batched_f32_mode(self, mode):
         """'exact' (f32 MFMA, the single-theta kernel's fmaf chain) or 'split' (three bfloat16 pieces, default)."""
         self.set_batched_f32_mode_raw({"exact": 0, "split": 1}[mode])

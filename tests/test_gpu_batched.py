@@ -95,6 +95,36 @@ def test_batched_f32_split_falls_back_when_theta_is_too_wide_for_lds():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_begin_end_equals_the_blocking_call(dtype):
+    """mhlik_loglik_batched_begin_* + _end: the same bits as the blocking call, and the context refuses any other
+    evaluation in between."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd._lib import MhlikError
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, K = 30000, 24, 40
+    X = synthetic_host(3, N, d)
+    Theta = np.random.default_rng(4).normal(0, 0.2, (K, d)).astype(dtype)
+    with Likelihood(N, d, precision=1 if dtype == np.float64 else 2) as lk:
+        lk.upload(X if dtype == np.float64 else np.asfortranarray(X.astype(np.float32)))
+        want = lk.loglik_batched(Theta, dtype=dtype)
+        with pytest.raises(MhlikError):
+            lk.loglik_batched_end()  # nothing begun
+        lk.loglik_batched_begin(Theta, dtype=dtype)
+        Theta_copy = Theta.copy()
+        Theta[:] = 0  # the caller's Theta has been copied by _begin
+        with pytest.raises(MhlikError):
+            lk.loglik_batched(Theta_copy, dtype=dtype)
+        with pytest.raises(MhlikError):
+            lk.loglik_batched_begin(Theta_copy, dtype=dtype)
+        with pytest.raises(MhlikError):
+            (lk.loglik if dtype == np.float64 else lk.loglik_f32)(Theta_copy[0])
+        got = lk.loglik_batched_end()
+        assert np.array_equal(got, want)
+        assert np.array_equal(lk.loglik_batched(Theta_copy, dtype=dtype), want)  # and the context is usable again
+
+
 def test_batched_overflow_column():
     from mcmc_amd import Likelihood
 

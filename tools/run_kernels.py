@@ -27,11 +27,16 @@ with Likelihood(N, 128, precision=3, segments=1) as lk:  # batched at d=128, K=6
     lk.fill_synthetic(12345)
     Th = rng.normal(0, 0.01, (64, 128))
     for _ in range(reps):
+        lk.set_batched_f32_mode("exact")  # f32 MFMA
+        lk.loglik_batched(Th.astype(np.float32), dtype=np.float32)
+        lk.set_batched_f32_mode("split")  # three bf16 pieces
         lk.loglik_batched(Th.astype(np.float32), dtype=np.float32)
         lk.loglik_batched(Th, dtype=np.float64)
     blocks = N // 64
-    lk.mp_reset_batched(64, blocks, 64)
     seeds = np.full(64, 1234, dtype=np.uint64)
-    for call in range(reps + 1):
-        lk.mp_loglik_batched(Th, 16, np.full(64, call % 16), seeds, call, 1.7e-7)
+    for mode in ("exact", "split"):
+        lk.set_batched_f32_mode(mode)
+        lk.mp_reset_batched(64, blocks, 64)
+        for call in range(reps + 1):
+            lk.mp_loglik_batched(Th, 16, np.full(64, call % 16), seeds, call, 1.7e-7)
 print("done")

@@ -113,5 +113,26 @@ int main(int argc, char **argv)
   RUNX3(6, 3, "x3 6 terms, no loads, plain sum")
   RUNX3(6, 5, "x3 loads only, plain sum")
   RUNX3(6, 0, "x3 6 terms (again)")
+  // occupancy experiments: loads only, one chain block (few registers), 2 / 4 / 8 workgroups per CU
+#define RUNOCC(PERCU, label) { auto k = lik_batched_x3_kernel<1, 6, 5>; \
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+    const long gr = ntiles < 256 * PERCU ? ntiles : 256 * PERCU; \
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(gr), dim3(256), (size_t)(lds3 / 4 + 4096), 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, 16, (int64_t)ntiles); }, reps); \
+    CK(hipDeviceSynchronize()); report(label, ms, true); }
+#define RUNPAT(EXPV, GRID, label) { auto k = lik_batched_x3_kernel<1, 6, EXPV>; \
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+    const long gr = (GRID); \
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(gr), dim3(256), (size_t)(lds3 / 4 + 4096), 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, 16, (int64_t)ntiles); }, reps); \
+    CK(hipDeviceSynchronize()); report(label, ms, true); }
+  RUNPAT(5, ntiles, "loads only, x3 pattern, 1 tile/WG")
+  RUNPAT(13, ntiles, "loads only, 1KB pattern, 1 tile/WG")
+  RUNPAT(13, 512, "loads only, 1KB pattern, 2 WG/CU")
+  RUNPAT(13, 1024, "loads only, 1KB pattern, 4 WG/CU")
+  RUNPAT(5, 1000, "loads only, x3 pattern, grid 1000")
+  RUNOCC(2, "loads only NB=1, 2 WG/CU")
+  RUNOCC(3, "loads only NB=1, 3 WG/CU")
+  RUNOCC(4, "loads only NB=1, 4 WG/CU")
+  RUNOCC(6, "loads only NB=1, 6 WG/CU")
+  RUNOCC(8, "loads only NB=1, 8 WG/CU")
   return 0;
 }
