@@ -290,14 +290,16 @@ __device__ __noinline__ MpbTerms mpb_pair_terms(float af, double ad, double eps,
 {
   const float sig_s = mhlik_sigmoidf_det(af);
   const double Bd = (double)sig_s - eps; // mcmc_mp.cu:63,146
-  const double L = 1.0 / (1.0 + exp(ad));
   MpbTerms t;
   if (bright) {
+    const double L = 1.0 / (1.0 + exp(ad));
     const float Bf = (float)Bd;
     t.rs = (double)logf(Bf) - log(L);
     t.lb = log(L - (double)Bf);
   } else {
-    t.rs = log(Bd) - log(L);
+    // a dark (re-examined) pair needs log L only: log(1/(1+e^x)) = -log(1+e^x) in one fused evaluation
+    // (mhlik_softplus.h, < 6e-16 relative) instead of exp, a division and a second log
+    t.rs = log(Bd) - mhlik_neg_softplus(ad);
     t.lb = 0.0;
   }
   return t;
@@ -531,6 +533,218 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__re
     // the next round's writes to the LDS tables come after its first barrier,
     // which every wave reaches only after this point
   }
+  acc_out[(int64_t)wave_global * kBatchCols + lane] = acc_b;
+  cnt_out[(int64_t)wave_global * kBatchCols + lane] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same correction when (nearly) every chain needs the same blocks -- all chains re-examine one phase
+// (mcmc_amd_mp_multichain_sampler's shared_phase), or everything is bright as in the first calls.  Then a block's
+// rows against the 64 thetas is a dense contraction and runs on the matrix cores instead of one row per lane
+// against four thetas broadcast from LDS (which is bound by the LDS return path: 12 bytes per lane per
+// multiply-add pair):
+//   float dots   v_mfma_f32_16x16x4_f32 -- bit-for-bit the column-ordered fmaf chain of the single-chain kernel
+//                (tools/check_mfma_order.hip), which log(L - B) needs: it is the log of a one-float-ulp difference;
+//   double dots  v_mfma_f64_16x16x4_f64 -- a fused chain, so within 1 ulp of the unfused mul+add chain of the
+//                single-chain kernel, not the same bits; it enters through L = 1/(1+e^x) only.
+// Work item = one 64-row segment of a block x one group of 16 chains, one wave.  A operand: lane (i = l&15,
+// g = l>>4) loads column j0+g; float: rows 4i..4i+3 (16 bytes, row set m = row 4i+m); double: rows 4s..4s+3 with
+// s = 4*(i&3) + (i>>2) (32 bytes).  The two MFMAs lay their results out differently (float: A-row 4g+r, double:
+// A-row g+4r in lane (c, g), register r); with that permutation of the double rows element (m, r) of both is
+// row 4*(4g+r)+m of the segment, chain 16*group + c.  Theta sits in LDS transposed ([column][64 chains]) so that
+// a B operand is one conflict-free read.  Per (row, chain) the same mpb_pair_terms as above; sums over a lane's 16
+// elements, then over the four lane groups, then over the block's segments, in that fixed order.
+// A workgroup (16 waves) owns the same contiguous run of blocks as in mpb_fix_kernel and takes R blocks per
+// round (R x segments x 4 items dealt to the waves in order); wave s then resamples block s of the round.
+constexpr int kMpbDenseItemsPerRound = kMpbFixBlock / kWave; // 16
+
+__device__ __forceinline__ double lanes_xor_sum_16_32(double v) // lanes c, c+16, c+32, c+48 -> (g0+g1)+(g2+g3)
+{
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float *__restrict__ Xf, TileGeom gf,
+                                                                     const double *__restrict__ Xd, TileGeom gd,
+                                                                     const double *__restrict__ Theta,
+                                                                     const float *__restrict__ Thetaf, int d_pad,
+                                                                     MpbParams p, const MpbChainArgs *__restrict__ ca,
+                                                                     int8_t *__restrict__ z, double *__restrict__ acc_out,
+                                                                     int32_t *__restrict__ cnt_out)
+{
+  typedef Vec16<float>::type F4;
+  typedef Vec16<double>::type D2;
+  constexpr int NW = kMpbFixBlock / kWave;
+  __shared__ double res_rs[NW][kBatchCols], res_lb[NW][kBatchCols];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *thdT = reinterpret_cast<double *>(smem);                                              // [d_pad][64]
+  float *thfT = reinterpret_cast<float *>(smem + sizeof(double) * (size_t)d_pad * kBatchCols);  // [d_pad][64]
+  for (int i = threadIdx.x; i < d_pad * kBatchCols; i += kMpbFixBlock) {
+    const int j = i >> 6, c = i & 63;
+    thdT[i] = c < p.K ? Theta[(size_t)c * d_pad + j] : 0.0;
+    thfT[i] = c < p.K ? Thetaf[(size_t)c * d_pad + j] : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave_global = blockIdx.x * NW + wave;
+  const int ai = lane & 15, ag = lane >> 4;
+  const int arow_f = 4 * ai, arow_d = 4 * (4 * (ai & 3) + (ai >> 2));
+  const int d = gf.d;
+  const int csf = (int)gf.col_stride, csd = (int)gd.col_stride;
+  const int64_t all = (int64_t)p.blocks << p.block_shift;
+  const int64_t covered = all < p.n_rows ? all : p.n_rows;
+  const int my_choose = ca->choose[lane];
+  const uint64_t my_seed = ca->seed[lane];
+  double acc_b = 0.0;
+  int32_t cnt = 0;
+
+  const int segs = p.block_rows >> 6;
+  const int per_block = segs * 4;                                   // items of one block
+  const int R = per_block >= NW ? 1 : NW / per_block;               // blocks per round (segs = 1: 4, 2: 2, else 1)
+  const int64_t chunk = ((int64_t)p.blocks + kMpbFixGroups - 1) / kMpbFixGroups;
+  const int64_t wg_begin = blockIdx.x * chunk;
+  const int64_t wg_end = wg_begin + chunk < p.blocks ? wg_begin + chunk : p.blocks;
+  __syncthreads();
+
+  // which chains need block b in double precision, and which are bright (lane k <-> chain k)
+  auto votes = [&](int64_t b, bool live, int8_t &zc, bool &bright, bool &need) {
+    zc = (live && lane < p.K) ? z[b * kBatchCols + lane] : (int8_t)0;
+    const bool has_rows = live && (b << p.block_shift) < p.n_rows;
+    bright = zc != 0;
+    const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
+    need = lane < p.K && has_rows && (bright || re);
+  };
+
+  // Blocks worth a visit, in index order: on the shared phase, or bright for some chain (a bright block without
+  // rows is visited only to be counted).  With 1/F of the blocks on the phase most are not, so the run is
+  // compacted first, 1024 blocks (one per thread) at a time, and the rounds walk the compacted list.
+  __shared__ int visit_list[kMpbFixBlock];
+  __shared__ int visit_count[NW];
+  const int choose0 = ca->choose[0];
+  for (int64_t base = wg_begin; base < wg_end; base += kMpbFixBlock) { // workgroup-uniform trip count
+  {
+    const int64_t b = base + threadIdx.x;
+    bool visit = false;
+    if (b < wg_end) {
+      const uint32_t *zw = reinterpret_cast<const uint32_t *>(z + b * kBatchCols);
+      uint32_t any = 0;
+#pragma unroll
+      for (int w = 0; w < kBatchCols / 4; w++) {
+        const int left = p.K - 4 * w; // chains of this word that exist (entries past K are never cleared)
+        const uint32_t mask = left >= 4 ? 0xffffffffu : (left > 0 ? (1u << (8 * left)) - 1u : 0u);
+        any |= zw[w] & mask;
+      }
+      visit = any != 0 || ((int)(b % p.resamp_factor) == choose0 && (b << p.block_shift) < p.n_rows);
+    }
+    const uint64_t vm = __ballot(visit);
+    if (lane == 0) visit_count[wave] = __builtin_popcountll(vm);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += visit_count[w];
+    if (visit) visit_list[before + __builtin_popcountll(vm & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
+  }
+  int n_visit = 0;
+  for (int w = 0; w < NW; w++) n_visit += visit_count[w];
+  __syncthreads();
+  for (int q0 = 0; q0 < n_visit; q0 += R) { // workgroup-uniform trip count
+    // ---- items ------------------------------------------------------------------
+    for (int it = wave; it < R * per_block; it += NW) {
+      const int slot = it / per_block, rem = it - slot * per_block;
+      const int seg = rem >> 2, grp = rem & 3;
+      if (q0 + slot >= n_visit) continue; // wave-uniform
+      const int64_t b = base + visit_list[q0 + slot];
+      int8_t zc;
+      bool bright, need;
+      votes(b, true, zc, bright, need);
+      const uint64_t nmask = __ballot(need), bmask = __ballot(bright);
+      const unsigned gmask = (unsigned)(nmask >> (16 * grp)) & 0xffffu;
+      if (gmask == 0) continue; // no chain of this group needs the block: its results are not read
+      const int chain = 16 * grp + ai;
+      const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
+      double s_rs = 0.0, s_lb = 0.0;
+      if (first < covered) { // wave-uniform
+        const float *pf = Xf + (first >> 10) * gf.tile_stride + (first & 1023) + arow_f;
+        const double *pd = Xd + (first >> 9) * gd.tile_stride + (first & 511) + arow_d;
+        const float *bf = thfT + chain;
+        const double *bd = thdT + chain;
+        f32x4 af[4];
+        f64x4 ad[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          af[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          ad[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+        }
+        // column of this lane in k-step j0: j0 + g, clamped to the last real column (its Theta entry is zero)
+        auto col = [&](int j0) { const int j = j0 + ag; return j < d ? j : d - 1; };
+        F4 xf = load16<float, false>(pf + (int64_t)col(0) * csf), nf = xf;
+        D2 xd0 = load16<double, false>(pd + (int64_t)col(0) * csd), xd1 = load16<double, false>(pd + (int64_t)col(0) * csd + 2);
+        D2 nd0 = xd0, nd1 = xd1;
+        for (int j0 = 0; j0 < d_pad; j0 += 4) {
+          if (j0 + 4 < d_pad) { // wave-uniform: the next k-step's rows are in flight under this one's MFMAs
+            const int jn = col(j0 + 4);
+            nf = load16<float, false>(pf + (int64_t)jn * csf);
+            nd0 = load16<double, false>(pd + (int64_t)jn * csd);
+            nd1 = load16<double, false>(pd + (int64_t)jn * csd + 2);
+          }
+          const float tb = bf[(j0 + ag) * kBatchCols];
+          const double tdv = bd[(j0 + ag) * kBatchCols];
+#pragma unroll
+          for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[m], tb, af[m], 0, 0, 0);
+          ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd0[0], tdv, ad[0], 0, 0, 0);
+          ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd0[1], tdv, ad[1], 0, 0, 0);
+          ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd1[0], tdv, ad[2], 0, 0, 0);
+          ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd1[1], tdv, ad[3], 0, 0, 0);
+          xf = nf;
+          xd0 = nd0;
+          xd1 = nd1;
+        }
+        // element (m, r): segment row 4*(4g + r) + m, chain 16*grp + c
+        if ((gmask >> ai) & 1u) {
+          const bool br = (bmask >> chain) & 1ull;
+#pragma unroll
+          for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              if (first + 4 * (4 * ag + r) + m < covered) {
+                const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, br);
+                s_rs += t.rs;
+                if (br) s_lb += t.lb;
+              }
+            }
+        }
+      }
+      s_rs = lanes_xor_sum_16_32(s_rs);
+      s_lb = lanes_xor_sum_16_32(s_lb);
+      if (ag == 0) {
+        res_rs[slot * segs + seg][chain] = s_rs;
+        res_lb[slot * segs + seg][chain] = s_lb;
+      }
+    }
+    __syncthreads();
+    // ---- resample, accumulate: wave s <-> block b0 + s, lane k <-> chain k ----------------
+    if (wave < R && q0 + wave < n_visit) {
+      const int64_t b = base + visit_list[q0 + wave];
+      int8_t zc;
+      bool bright, need;
+      votes(b, true, zc, bright, need);
+      if (need) {
+        double rs = 0.0, lb = 0.0;
+        for (int seg = 0; seg < segs; seg++) {
+          rs += res_rs[wave * segs + seg][lane];
+          lb += res_lb[wave * segs + seg][lane];
+        }
+        const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
+        const double p_bright = 1.0 - exp(rs);
+        const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
+        if (bright) acc_b += lb;
+        if (zn != zc) z[b * kBatchCols + lane] = zn;
+        zc = zn;
+      }
+      cnt += zc != 0 ? 1 : 0;
+    }
+    __syncthreads(); // the next round overwrites the result tables
+  }
+  } // 1024-block window (its last barrier also orders the list's reuse)
   acc_out[(int64_t)wave_global * kBatchCols + lane] = acc_b;
   cnt_out[(int64_t)wave_global * kBatchCols + lane] = cnt;
 }

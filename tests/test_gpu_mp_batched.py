@@ -40,9 +40,12 @@ CASES = [
 ]
 
 
+# one phase for all chains: with K >= 16 the correction runs as a dense contraction on the matrix cores
+# (mpb_fix_dense_kernel) instead of the per-(block, chain) kernel; the definition per chain is the same
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("mode", ["exact", "split"])  # float dots of the dark pass: f32 MFMA / three bf16 pieces
-@pytest.mark.parametrize("N,d,block_rows,blocks,K,rf", CASES)
-def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, K, rf, mode):
+@pytest.mark.parametrize("N,d,block_rows,blocks,K,rf", CASES + [(70000, 24, 512, None, 64, 3), (6000, 9, 64, 40, 16, 2)])
+def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, K, rf, mode, shared):
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
 
@@ -61,6 +64,8 @@ def test_mp_batched_sequence_matches_oracle_per_chain(N, d, block_rows, blocks, 
         for call in range(5):
             Th = rng.normal(0, 0.5 / np.sqrt(d), (K, d))
             choose = rng.integers(0, rf, K).astype(np.int32)
+            if shared:
+                choose[:] = choose[0]
             got, gb, gd = lk.mp_loglik_batched(Th, rf, choose, seeds, call, eps)
             for k in range(K):
                 want, wb, wd = _oracle_mp(X, Xf, Th[k], block_rows, blocks, rf, int(choose[k]), int(seeds[k]), call,
