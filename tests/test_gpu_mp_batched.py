@@ -167,3 +167,19 @@ def test_mp_multichain_sampler_shared_phase_runs_and_keeps_streams():
     # chain 0 re-examines its own phase either way: identical trajectory
     assert np.array_equal(a["samples"][0], b["samples"][0])
     assert (a["bright"] >= 0).all() and (a["bright"] <= N // 64).all()
+
+
+def test_mfma_16x16x4_f32_is_the_column_ordered_fmaf_chain():
+    """mpb_fix_dense_kernel forms the float dots of bright / re-examined rows with v_mfma_f32_16x16x4_f32 and
+    relies on it being, bit for bit, the k-ordered fmaf chain of the single-chain kernel with the result rows
+    4*(lane>>4)+r in a lane (the double MFMA: rows (lane>>4)+4*r): tools/check_mfma_order."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_mfma_order")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    assert "row=4*(l>>4)+r: f32 16x16x4 == k-ordered fmaf chain on 256/256" in lines[0], out.stdout
+    assert "f64 16x16x4 == fma chain on 256/256" in lines[1], out.stdout
