@@ -297,9 +297,15 @@ __device__ __noinline__ MpbTerms mpb_pair_terms(float af, double ad, double eps,
     t.rs = (double)logf(Bf) - log(L);
     t.lb = log(L - (double)Bf);
   } else {
-    // a dark (re-examined) pair needs log L only: log(1/(1+e^x)) = -log(1+e^x) in one fused evaluation
-    // (mhlik_softplus.h, < 6e-16 relative) instead of exp, a division and a second log
-    t.rs = log(Bd) - mhlik_neg_softplus(ad);
+    // A dark (re-examined) pair needs log B - log L = log1p(B/L - 1) only, and B/L - 1 = B(1 + e^x) - 1 is of
+    // the order of the float sigmoid's error (~1e-7): one exp, one fma and a four-term series (next term
+    // < 2e-16 relative) replace exp, a division and two logs; the absolute error (~1e-16) is that of the two
+    // logs.  Anything else (B <= 0 at the far tails, overflow of e^x, NaN) takes the definition itself.
+    const double u = fma(Bd, exp(ad), Bd - 1.0);
+    if (fabs(u) < 0x1p-10)
+      t.rs = u * (1.0 - u * (0.5 - u * (1.0 / 3.0 - u * 0.25)));
+    else
+      t.rs = log(Bd) - mhlik_neg_softplus(ad); // log(1/(1+e^x)) = -log(1+e^x), mhlik_softplus.h
     t.lb = 0.0;
   }
   return t;
@@ -676,28 +682,38 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
         }
         // column of this lane in k-step j0: j0 + g, clamped to the last real column (its Theta entry is zero)
         auto col = [&](int j0) { const int j = j0 + ag; return j < d ? j : d - 1; };
-        F4 xf = load16<float, false>(pf + (int64_t)col(0) * csf), nf = xf;
-        D2 xd0 = load16<double, false>(pd + (int64_t)col(0) * csd), xd1 = load16<double, false>(pd + (int64_t)col(0) * csd + 2);
-        D2 nd0 = xd0, nd1 = xd1;
-        for (int j0 = 0; j0 < d_pad; j0 += 4) {
-          if (j0 + 4 < d_pad) { // wave-uniform: the next k-step's rows are in flight under this one's MFMAs
-            const int jn = col(j0 + 4);
-            nf = load16<float, false>(pf + (int64_t)jn * csf);
-            nd0 = load16<double, false>(pd + (int64_t)jn * csd);
-            nd1 = load16<double, false>(pd + (int64_t)jn * csd + 2);
-          }
+        // two k-steps of rows in flight: buffers A and B alternate, each reloaded right after the MFMAs that
+        // read it have been issued (no copies, so a load has two k-steps of MFMAs to land under)
+        auto loadk = [&](int j0, F4 &f, D2 &a0, D2 &a1) {
+          const int j = col(j0);
+          f = load16<float, false>(pf + (int64_t)j * csf);
+          a0 = load16<double, false>(pd + (int64_t)j * csd);
+          a1 = load16<double, false>(pd + (int64_t)j * csd + 2);
+        };
+        auto mfmak = [&](int j0, const F4 &f, const D2 &a0, const D2 &a1) {
           const float tb = bf[(j0 + ag) * kBatchCols];
           const double tdv = bd[(j0 + ag) * kBatchCols];
 #pragma unroll
-          for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[m], tb, af[m], 0, 0, 0);
-          ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd0[0], tdv, ad[0], 0, 0, 0);
-          ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd0[1], tdv, ad[1], 0, 0, 0);
-          ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd1[0], tdv, ad[2], 0, 0, 0);
-          ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd1[1], tdv, ad[3], 0, 0, 0);
-          xf = nf;
-          xd0 = nd0;
-          xd1 = nd1;
+          for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[m], tb, af[m], 0, 0, 0);
+          ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], tdv, ad[0], 0, 0, 0);
+          ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], tdv, ad[1], 0, 0, 0);
+          ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], tdv, ad[2], 0, 0, 0);
+          ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], tdv, ad[3], 0, 0, 0);
+        };
+        const int nk = d_pad >> 2;
+        F4 fA, fB;
+        D2 a0A, a1A, a0B, a1B;
+        loadk(0, fA, a0A, a1A);
+        fB = fA, a0B = a0A, a1B = a1A;
+        if (nk > 1) loadk(4, fB, a0B, a1B);
+        int k = 0;
+        for (; k + 2 <= nk; k += 2) {
+          mfmak(4 * k, fA, a0A, a1A);
+          if (k + 2 < nk) loadk(4 * (k + 2), fA, a0A, a1A);
+          mfmak(4 * (k + 1), fB, a0B, a1B);
+          if (k + 3 < nk) loadk(4 * (k + 3), fB, a0B, a1B);
         }
+        if (k < nk) mfmak(4 * k, fA, a0A, a1A);
         // element (m, r): segment row 4*(4g + r) + m, chain 16*grp + c
         if ((gmask >> ai) & 1u) {
           const bool br = (bmask >> chain) & 1ull;
