@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--data-seed", type=int, default=12345)
     ap.add_argument("--cpu-iters", type=int, default=60, help="MH iterations of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the SP / multi-core side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the SP / multi-core / N=100M side measurements")
+    ap.add_argument("--big-rows", type=int, default=100_000_000,
+                    help="rows of the BASELINE configs[3] side measurement (0 = skip)")
     ap.add_argument("--workload", default="mh", choices=["mh", "batched_f32", "batched_f64", "mp_batched"],
                     help="mh (default): BASELINE's metric, the DP MH step at N=10M d=64.  The others time BASELINE "
                          "configs[4] (64 lock-step chains, X.Theta on MFMA, N=10M d=128) on one GPU")
@@ -159,39 +161,51 @@ def main():
         torch.cuda.synchronize()
 
     N, d = a.rows, a.cols
-    lk = Likelihood(N, d, precision=F64, device=local_rank, rank=rank, world=world, timing=True)
-    lk.fill_synthetic(a.data_seed)
-    in_library_rccl = True
-    if world > 1:
-        # the in-library path: ncclAllReduce on the context's stream, inside the device-resident chain
-        failed = 0
-        try:
-            if os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
-                raise RuntimeError("fallback forced")
-            idt = torch.zeros(128, dtype=torch.uint8, device=red_dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            lk.comm_init(bytes(idt.cpu().numpy().tobytes()))
-        except Exception as e:  # noqa: BLE001 -- reported below, on every rank
-            print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
-            failed = 1
-        t = torch.tensor([failed], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        in_library_rccl = int(t.item()) == 0
-    elif os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
-        in_library_rccl = False
 
+    def make_context(rows):
+        """The sharded double-precision context of this rank with device-generated data, and whether the
+        in-library RCCL communicator is up on every rank (else the fallback host loop is used)."""
+        ctx = Likelihood(rows, d, precision=F64, device=local_rank, rank=rank, world=world, timing=True)
+        ctx.fill_synthetic(a.data_seed)
+        ok = True
+        if world > 1:
+            # the in-library path: ncclAllReduce on the context's stream, inside the device-resident chain
+            failed = 0
+            try:
+                if os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
+                    raise RuntimeError("fallback forced")
+                idt = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                ctx.comm_init(bytes(idt.cpu().numpy().tobytes()))
+            except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                failed = 1
+            t = torch.tensor([failed], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ok = int(t.item()) == 0
+        elif os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
+            ok = False
+        return ctx, ok
+
+    def timed_chain(ctx, ok, rows, steps, warmup):
+        """warmup burn-in iterations, then exactly `steps` timed MH iterations; max over ranks."""
+        step_sd = 2.38 / np.sqrt(d) * 2e-3  # small random-walk step: the posterior at N=1e7 is narrow
+        if ok:
+            el, kms, acc = run_c_sampler(a, ctx, S, np, rows, d, steps, warmup, step_sd, barrier)
+        else:
+            el, kms, acc = run_host_loop(a, ctx, S, np, torch, dist, red_dev, world, d, steps, warmup, step_sd, barrier)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, kms, acc
+
+    lk, in_library_rccl = make_context(N)
     K, W = a.steps, a.warmup
-    rwsd = 2.38 / np.sqrt(d) * 2e-3  # small random-walk step: the posterior at N=1e7 is narrow
-    if in_library_rccl:
-        elapsed, kernel_ms, n_accepted = run_c_sampler(a, lk, S, np, N, d, K, W, rwsd, barrier)
-    else:
-        elapsed, kernel_ms, n_accepted = run_host_loop(a, lk, S, np, torch, dist, red_dev, world, d, K, W, rwsd, barrier)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rwsd = 2.38 / np.sqrt(d) * 2e-3
+    elapsed, kernel_ms, n_accepted = timed_chain(lk, in_library_rccl, N, K, W)
 
     info = lk.info()
     local_bytes = info["local_rows"] * d * 8
@@ -231,6 +245,24 @@ def main():
         if a.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(a, np, N, d, rwsd, lk, S)
     lk.close()
+
+    # ---- BASELINE configs[3] beside the metric's size, at every GPU count: N=100M, d=64, the same rows sharded ---
+    if not a.no_extras and (N, d) == (10_000_000, 64) and a.big_rows > 0:
+        big = {"rows": a.big_rows, "cols": d}
+        try:
+            ctx, ok = make_context(a.big_rows)  # 51.2 GB on one GPU, 6.4 GB per GPU on 8
+            steps_big = max(20, min(K, 100))
+            el, kms, _ = timed_chain(ctx, ok, a.big_rows, steps_big, 3)
+            rows_local = ctx.info()["local_rows"]
+            ctx.close()
+            big.update({"it_per_s": steps_big / el, "ms_per_step": el / steps_big * 1e3, "steps": steps_big,
+                        "kernel_ms": kms, "rows_per_gpu": rows_local,
+                        "kernel_GBps": rows_local * d * 8 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                        "likelihood_GBps_whole_job": a.big_rows * d * 8 / (el / steps_big) / 1e9,
+                        "in_library_rccl": bool(ok)})
+        except Exception as e:  # noqa: BLE001 -- a side measurement never costs the main line
+            big["error"] = str(e)
+        out.setdefault("extra", {})["n100m"] = big
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
