@@ -168,7 +168,6 @@ struct mhlik_ctx {
   int32_t *mpb_cnt = nullptr;   // [kMpbFixWaves][64] bright counts
   double *mpb_theta = nullptr;  // [64][d] row-major
   float *mpb_thetaf = nullptr;
-  void *mpb_args = nullptr;     // device MpbChainArgs
   double *mpb_res = nullptr, *mpb_res_dev = nullptr; // pinned host [64][4] and its device view
 
   void *stats_buf = nullptr; // chain statistics scratch (mhlik_stats.hpp)

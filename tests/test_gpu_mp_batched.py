@@ -183,3 +183,41 @@ def test_mfma_16x16x4_f32_is_the_column_ordered_fmaf_chain():
     lines = out.stdout.splitlines()
     assert "row=4*(l>>4)+r: f32 16x16x4 == k-ordered fmaf chain on 256/256" in lines[0], out.stdout
     assert "f64 16x16x4 == fma chain on 256/256" in lines[1], out.stdout
+
+
+def test_mp_batched_begin_end_equals_the_blocking_call():
+    """mhlik_mp_loglik_batched_begin + _end on one context against the blocking call on a twin context (the
+    indicators evolve with every call, so the two run side by side); no other evaluation between the halves."""
+    import ctypes as C
+
+    from mcmc_amd import Likelihood, _lib as L
+    from mcmc_amd._lib import MhlikError
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, K, rf, eps = 16384, 6, 20, 4, 1.7e-7
+    blocks = N // 64
+    X = synthetic_host(11, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    seeds = np.arange(50, 50 + K, dtype=np.uint64)
+    rng = np.random.default_rng(8)
+    with Likelihood(N, d, precision=3, segments=1) as a, Likelihood(N, d, precision=3, segments=1) as b:
+        for lk in (a, b):
+            lk.upload(X)
+            lk.upload(Xf)
+            lk.mp_reset_batched(64, blocks, K)
+        lib = L.load_mhlik()
+        for call in range(4):
+            Th = np.ascontiguousarray(rng.normal(0, 0.2, (K, d)))
+            choose = np.full(K, rng.integers(0, rf), dtype=np.int32) if call % 2 else rng.integers(0, rf, K).astype(np.int32)
+            want, wb, wd = a.mp_loglik_batched(Th, rf, choose, seeds, call, eps)
+            st = L.MpBatch(64, blocks, rf, K, choose.ctypes.data, seeds.ctypes.data, call, eps)
+            assert lib.mhlik_mp_loglik_batched_begin(b.handle, C.byref(st), Th.ctypes.data) == 0
+            with pytest.raises(MhlikError):
+                b.loglik(Th[0])  # the context is busy until _end
+            with pytest.raises(MhlikError):
+                b.mp_indicators_batched()
+            got, nb, nd = np.empty(K), np.empty(K, dtype=np.int32), np.empty(K, dtype=np.int32)
+            assert lib.mhlik_mp_loglik_batched_end(b.handle, got.ctypes.data, nb.ctypes.data, nd.ctypes.data) == 0
+            assert np.array_equal(got, want) and np.array_equal(nb, wb) and np.array_equal(nd, wd)
+            assert np.array_equal(a.mp_indicators_batched(), b.mp_indicators_batched())
+        assert lib.mhlik_mp_loglik_batched_end(b.handle, got.ctypes.data, None, None) != 0  # nothing begun
