@@ -80,7 +80,7 @@ __device__ __forceinline__ void x3_split(const V4 (&x)[8], int m, bf16x8 &fa, bf
 // The pipeline also runs on across the tiles a workgroup owns (tile0, tile0 + tile_step, ... < ntiles), so
 // Theta is staged into LDS once per workgroup and the load queue never drains.  tile_done(tile) runs after the
 // last pass of a tile (all four waves reach it the same number of times: it may use barriers).
-template <int NB, int TERMS, int EXP, class Epi, class Done>
+template <int NB, int TERMS, int EXP, int NBUF = 2, class Epi, class Done>
 __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, int64_t tile_stride, int64_t tile0,
                                                   int64_t tile_step, int64_t ntiles, int wave, int64_t col_stride,
                                                   int d, int d_pad, const u32x4 *thetaL, int lane, Epi epi,
@@ -101,7 +101,7 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
 #pragma unroll
       for (int n = 0; n < NB; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  V4 x[8], y[8];
+  V4 x[8], y[8], z[NBUF == 3 ? 8 : 1];
   auto load_block = [&](V4 (&buf)[8], int64_t tile, int pass, int kb) {
     const float *ubase = X + tile * tile_stride + pass * 256 + wave * 64;
     if (EXP & 8) { // lab: the same bytes as 1 KB-contiguous wave loads (column (pass*nkb + kb)*8 + u, rows 256*wave + 4*lane)
@@ -170,7 +170,68 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
       }
     }
   };
+  // Interleaved form (EXP & 16): the split of row set m+1 is issued between the MFMAs of row set m, so the VALU work
+  // of the split hides under the matrix pipe inside one wave (an MFMA occupies the issue port 4 of its 16 cycles).
+  // Row set outermost, so all of the block's Theta fragments stay in registers for its duration; only two row
+  // sets' fragments are live at a time.  Per accumulator the MFMAs come in the same order as in mfma_block.
+  auto mfma_rowset = [&](int m, const bf16x8 (&T)[NB][3], const bf16x8 &a, const bf16x8 &b, const bf16x8 &c3) {
+    f32x4 c[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = acc[m][n];
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c3, T[n][0], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, T[n][1], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, T[n][2], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, T[n][0], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, T[n][1], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, T[n][0], c[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) acc[m][n] = c[n];
+  };
+  auto finish_ilv = [&](V4 (&buf)[8], bool more) {
+    static_assert(!(EXP & 16) || TERMS == 6, "the interleaved form is written for six terms");
+    bf16x8 T[NB][3];
+    const u32x4 *tb = thetaL + (size_t)w.kb * NB * 3 * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < NB; n++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) T[n][t] = __builtin_bit_cast(bf16x8, tb[(n * 3 + t) * 64]);
+    bf16x8 a0, b0, c0, a1, b1, c1;
+    x3_split(buf, 0, a0, b0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_split(buf, 1, a1, b1, c1); // under the MFMAs of row set 0
+    mfma_rowset(0, T, a0, b0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_split(buf, 2, a0, b0, c0);
+    mfma_rowset(1, T, a1, b1, c1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_split(buf, 3, a1, b1, c1);
+    mfma_rowset(2, T, a0, b0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { // the buffer has been read out: request its successor-but-one
+      load_block(buf, l.tile, l.pass, l.kb);
+      advance(l);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_rowset(3, T, a1, b1, c1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (w.kb == nkb - 1) {
+      epi(w.tile, w.pass * 256 + wave * 64, acc);
+      zero_acc();
+      if (w.pass == 3) tile_done(w.tile);
+    }
+    advance(w);
+  };
   auto finish = [&](V4 (&buf)[8], bool more) { // work on the block in buf; request its successor-but-one
+    if constexpr ((EXP & 16) != 0) {
+      finish_ilv(buf, more);
+      return;
+    }
     if (EXP & 4) { // lab: loads only
 #pragma unroll
       for (int u = 0; u < 8; u++)
@@ -205,19 +266,38 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
     advance(l);
     load_block(y, l.tile, l.pass, l.kb);
     advance(l);
+    if constexpr (NBUF == 3) {
+      load_block(z, l.tile, l.pass, l.kb);
+      advance(l);
+    }
   }
-  for (int64_t b = 0; b + 3 < total; b += 2) {
-    finish(x, true);
-    finish(y, true);
+  if constexpr (NBUF == 3) { // three blocks in flight; total >= 4
+    int64_t b = 0;
+    for (; b + 6 <= total; b += 3) {
+      finish(x, true);
+      finish(y, true);
+      finish(z, true);
+    }
+    const int rem = (int)(total - b); // 3, 4 or 5 blocks left, rem - 3 of them not yet requested
+    finish(x, rem > 3);
+    finish(y, rem > 4);
+    finish(z, false);
+    if (rem > 3) finish(x, false);
+    if (rem > 4) finish(y, false);
+  } else {
+    for (int64_t b = 0; b + 3 < total; b += 2) {
+      finish(x, true);
+      finish(y, true);
+    }
+    finish(x, false);
+    finish(y, false);
   }
-  finish(x, false);
-  finish(y, false);
 }
 
 // Workgroup = 4 waves; grid = a fixed number of workgroups (2 per CU), workgroup g takes the 1024-row tiles
 // g, g + gridDim.x, ...  NB = number of 16-chain blocks (1..4).  theta_dev: the LDS image
 // (d_pad/32 * NB * 3 * 64 * 16 bytes).  Partials as lik_batched_f32_kernel: partials[chain*pstride + tile].
-template <int NB, int TERMS, int EXP = 0>
+template <int NB, int TERMS, int EXP = 0, int NBUF = 2>
 __global__ __launch_bounds__(kBlock, 2) void lik_batched_x3_kernel(const float *__restrict__ X, TileGeom g,
                                                                    const int32_t *__restrict__ tile_valid,
                                                                    const u32x4 *__restrict__ theta_dev, int d_pad,
@@ -272,8 +352,8 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_x3_kernel(const float *
     }
     __syncthreads();
   };
-  batched_x3_stream<NB, TERMS, EXP>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave, g.col_stride,
-                                    g.d, d_pad, thetaL, lane, epi, tile_done);
+  batched_x3_stream<NB, TERMS, EXP, NBUF>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave,
+                                          g.col_stride, g.d, d_pad, thetaL, lane, epi, tile_done);
 }
 
 // piece t (0, 1, 2) of v as a truncated bfloat16: the top 16 bits of v, of v - piece 0, of v - piece 0 - piece 1

@@ -113,6 +113,14 @@ int main(int argc, char **argv)
   RUNX3(6, 3, "x3 6 terms, no loads, plain sum")
   RUNX3(6, 5, "x3 loads only, plain sum")
   RUNX3(6, 0, "x3 6 terms (again)")
+#define RUNX3B(label) { auto k = lik_batched_x3_kernel<4, 6, 0, 3>; \
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 512 ? ntiles : 512), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
+    CK(hipDeviceSynchronize()); report(label, ms, false); }
+  RUNX3B("x3 6 terms, three load buffers")
+  RUNX3(6, 16, "x3 6 terms, split under the MFMAs")
+  RUNX3(6, 0, "x3 6 terms (plain again)")
+  RUNX3(6, 16, "x3 6 terms, split under the MFMAs")
   // occupancy experiments: loads only, one chain block (few registers), 2 / 4 / 8 workgroups per CU
 #define RUNOCC(PERCU, label) { auto k = lik_batched_x3_kernel<1, 6, 5>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
