@@ -230,23 +230,30 @@ struct SegDesc {
   int32_t pad;
 };
 
-// p[first] + p[first+STRIDE] + ... (< count), added in that order.  Eight loads
-// are put in flight together; slots past the end contribute +0.0, which leaves
-// the running sum's bits alone.
-template <int STRIDE> __device__ __forceinline__ double strided_sum(const double *__restrict__ p, int first, int64_t count)
+// p[first] + p[first+STRIDE] + ... (< count), added in that order.  UN loads are put in flight together; slots past
+// the end contribute +0.0, which leaves the running sum's bits alone, so the bits do not depend on UN.
+template <int STRIDE, int UN>
+__device__ __forceinline__ double strided_sum_batched(const double *__restrict__ p, int first, int64_t count)
 {
   double v = 0.0;
-  for (int64_t t = first; t < count; t += (int64_t)STRIDE * 8) {
-    double x[8];
+  for (int64_t t = first; t < count; t += (int64_t)STRIDE * UN) {
+    double x[UN];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < UN; u++) {
       const int64_t i = t + (int64_t)u * STRIDE;
       x[u] = i < count ? p[i] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) v += x[u];
+    for (int u = 0; u < UN; u++) v += x[u];
   }
   return v;
+}
+// Long runs take 40 loads per batch: a segment of the N=10M job (2441 tiles, 38 per lane of a wave) is one round
+// trip to memory instead of five.  Short runs keep batches of 8 (fewer predicated-off loads).
+template <int STRIDE> __device__ __forceinline__ double strided_sum(const double *__restrict__ p, int first, int64_t count)
+{
+  return count > (int64_t)STRIDE * 8 ? strided_sum_batched<STRIDE, 40>(p, first, count)
+                                     : strided_sum_batched<STRIDE, 8>(p, first, count);
 }
 
 constexpr int kSegBlock = 1024;                   // threads of the segment kernel
