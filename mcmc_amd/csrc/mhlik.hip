@@ -547,6 +547,7 @@ template <typename T> int loglik_impl(mhlik_ctx *c, const T *theta, double *out,
 template <typename T> int upload_impl(mhlik_ctx *c, const T *X, int64_t ld, int64_t row0)
 {
   if (!c) return MHLIK_EINVAL;
+  NOT_PENDING(c);
   if (!X) return fail(c, MHLIK_EINVAL, "X must not be NULL");
   if (!(c->cfg.precision & (sizeof(T) == 8 ? MHLIK_F64 : MHLIK_F32)))
     return fail(c, MHLIK_EINVAL, "context was not created with this precision");
@@ -599,6 +600,7 @@ template <typename T> int upload_impl(mhlik_ctx *c, const T *X, int64_t ld, int6
 template <typename T> int download_impl(mhlik_ctx *c, T *X, int64_t ld)
 {
   if (!c) return MHLIK_EINVAL;
+  NOT_PENDING(c);
   if (!X) return fail(c, MHLIK_EINVAL, "X must not be NULL");
   Store &s = store_of<T>(c);
   if (!s.has_data) return fail(c, MHLIK_ESTATE, "nothing to download");
@@ -771,6 +773,7 @@ int mhlik_download_f32(mhlik_ctx *c, float *X, int64_t ld) { return download_imp
 int mhlik_fill_synthetic(mhlik_ctx *c, uint64_t seed)
 {
   if (!c) return MHLIK_EINVAL;
+  NOT_PENDING(c);
   HIPCHK(c, hipSetDevice(c->device));
   if (c->cfg.precision & MHLIK_F64) {
     int rc = fill_impl<double>(c, seed);
@@ -826,6 +829,7 @@ int mhlik_loglik_f32(mhlik_ctx *c, const float *theta, float *out)
 int mhlik_rowdots_f64(mhlik_ctx *c, const double *theta, double *out)
 {
   if (!c) return MHLIK_EINVAL;
+  NOT_PENDING(c);
   if (!out) return fail(c, MHLIK_EINVAL, "out must not be NULL");
   Store &s = c->s64;
   if (!s.has_data) return fail(c, MHLIK_ESTATE, "no float64 design matrix on the device");

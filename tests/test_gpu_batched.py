@@ -120,6 +120,10 @@ def test_batched_begin_end_equals_the_blocking_call(dtype):
             lk.loglik_batched_begin(Theta_copy, dtype=dtype)
         with pytest.raises(MhlikError):
             (lk.loglik if dtype == np.float64 else lk.loglik_f32)(Theta_copy[0])
+        with pytest.raises(MhlikError):  # nor may the matrix change under the running pass
+            lk.upload(X if dtype == np.float64 else np.asfortranarray(X.astype(np.float32)))
+        with pytest.raises(MhlikError):
+            lk.fill_synthetic(1)
         got = lk.loglik_batched_end()
         assert np.array_equal(got, want)
         assert np.array_equal(lk.loglik_batched(Theta_copy, dtype=dtype), want)  # and the context is usable again
