@@ -560,10 +560,10 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__re
 // row 4*(4g+r)+m of the segment, chain 16*group + c.  Theta sits in LDS transposed ([column][64 chains]) so that
 // a B operand is one conflict-free read.  Per (row, chain) the same mpb_pair_terms as above; sums over a lane's 16
 // elements, then over the four lane groups, then over the block's segments, in that fixed order.
-// A workgroup (16 waves) owns the same contiguous run of blocks as in mpb_fix_kernel and takes R blocks per
-// round (R x segments x 4 items dealt to the waves in order); wave s then resamples block s of the round.
-constexpr int kMpbDenseItemsPerRound = kMpbFixBlock / kWave; // 16
-
+// A workgroup (16 waves) owns the same contiguous run of blocks as in mpb_fix_kernel.  Wave w serves chain group
+// w & 3 and every fourth block worth a visit (w >> 2 picks which): it walks the block's segments, adds up its 16
+// chains' terms and resamples those 16 indicators itself, so no wave waits for another (no barriers, no result
+// tables in LDS) and the waves of a SIMD drift apart, one's epilogue under another's MFMAs.
 __device__ __forceinline__ double lanes_xor_sum_16_32(double v) // lanes c, c+16, c+32, c+48 -> (g0+g1)+(g2+g3)
 {
   v += __shfl_xor(v, 16);
@@ -582,7 +582,6 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
   typedef Vec16<float>::type F4;
   typedef Vec16<double>::type D2;
   constexpr int NW = kMpbFixBlock / kWave;
-  __shared__ double res_rs[NW][kBatchCols], res_lb[NW][kBatchCols];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *thdT = reinterpret_cast<double *>(smem);                                              // [d_pad][64]
   float *thfT = reinterpret_cast<float *>(smem + sizeof(double) * (size_t)d_pad * kBatchCols);  // [d_pad][64]
@@ -599,170 +598,142 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
   const int csf = (int)gf.col_stride, csd = (int)gd.col_stride;
   const int64_t all = (int64_t)p.blocks << p.block_shift;
   const int64_t covered = all < p.n_rows ? all : p.n_rows;
-  const int my_choose = ca->choose[lane];
-  const uint64_t my_seed = ca->seed[lane];
+  const int grp = wave & 3, quarter = wave >> 2;
+  const int chain = 16 * grp + ai; // the four lane groups hold replicas of everything that is per chain
+  const bool chain_live = chain < p.K;
+  const int my_choose = ca->choose[chain];
+  const uint64_t my_seed = ca->seed[chain];
+  const float *bf = thfT + chain;
+  const double *bd = thdT + chain;
   double acc_b = 0.0;
   int32_t cnt = 0;
 
   const int segs = p.block_rows >> 6;
-  const int per_block = segs * 4;                                   // items of one block
-  const int R = per_block >= NW ? 1 : NW / per_block;               // blocks per round (segs = 1: 4, 2: 2, else 1)
   const int64_t chunk = ((int64_t)p.blocks + kMpbFixGroups - 1) / kMpbFixGroups;
   const int64_t wg_begin = blockIdx.x * chunk;
   const int64_t wg_end = wg_begin + chunk < p.blocks ? wg_begin + chunk : p.blocks;
-  __syncthreads();
-
-  // which chains need block b in double precision, and which are bright (lane k <-> chain k)
-  auto votes = [&](int64_t b, bool live, int8_t &zc, bool &bright, bool &need) {
-    zc = (live && lane < p.K) ? z[b * kBatchCols + lane] : (int8_t)0;
-    const bool has_rows = live && (b << p.block_shift) < p.n_rows;
-    bright = zc != 0;
-    const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
-    need = lane < p.K && has_rows && (bright || re);
-  };
 
   // Blocks worth a visit, in index order: on the shared phase, or bright for some chain (a bright block without
   // rows is visited only to be counted).  With 1/F of the blocks on the phase most are not, so the run is
-  // compacted first, 1024 blocks (one per thread) at a time, and the rounds walk the compacted list.
+  // compacted first, 1024 blocks (one per thread) at a time.
   __shared__ int visit_list[kMpbFixBlock];
   __shared__ int visit_count[NW];
   const int choose0 = ca->choose[0];
   for (int64_t base = wg_begin; base < wg_end; base += kMpbFixBlock) { // workgroup-uniform trip count
-  {
-    const int64_t b = base + threadIdx.x;
-    bool visit = false;
-    if (b < wg_end) {
-      const uint32_t *zw = reinterpret_cast<const uint32_t *>(z + b * kBatchCols);
-      uint32_t any = 0;
+    {
+      const int64_t b = base + threadIdx.x;
+      bool visit = false;
+      if (b < wg_end) {
+        const uint32_t *zw = reinterpret_cast<const uint32_t *>(z + b * kBatchCols);
+        uint32_t any = 0;
 #pragma unroll
-      for (int w = 0; w < kBatchCols / 4; w++) {
-        const int left = p.K - 4 * w; // chains of this word that exist (entries past K are never cleared)
-        const uint32_t mask = left >= 4 ? 0xffffffffu : (left > 0 ? (1u << (8 * left)) - 1u : 0u);
-        any |= zw[w] & mask;
+        for (int w = 0; w < kBatchCols / 4; w++) {
+          const int left = p.K - 4 * w; // chains of this word that exist (entries past K are never cleared)
+          const uint32_t mask = left >= 4 ? 0xffffffffu : (left > 0 ? (1u << (8 * left)) - 1u : 0u);
+          any |= zw[w] & mask;
+        }
+        visit = any != 0 || ((int)(b % p.resamp_factor) == choose0 && (b << p.block_shift) < p.n_rows);
       }
-      visit = any != 0 || ((int)(b % p.resamp_factor) == choose0 && (b << p.block_shift) < p.n_rows);
+      const uint64_t vm = __ballot(visit);
+      if (lane == 0) visit_count[wave] = __builtin_popcountll(vm);
+      __syncthreads(); // also orders the LDS copy of Theta before its first use
+      int before = 0;
+      for (int w = 0; w < wave; w++) before += visit_count[w];
+      if (visit) visit_list[before + __builtin_popcountll(vm & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
     }
-    const uint64_t vm = __ballot(visit);
-    if (lane == 0) visit_count[wave] = __builtin_popcountll(vm);
+    int n_visit = 0;
+    for (int w = 0; w < NW; w++) n_visit += visit_count[w];
     __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wave; w++) before += visit_count[w];
-    if (visit) visit_list[before + __builtin_popcountll(vm & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
-  }
-  int n_visit = 0;
-  for (int w = 0; w < NW; w++) n_visit += visit_count[w];
-  __syncthreads();
-  for (int q0 = 0; q0 < n_visit; q0 += R) { // workgroup-uniform trip count
-    // ---- items ------------------------------------------------------------------
-    for (int it = wave; it < R * per_block; it += NW) {
-      const int slot = it / per_block, rem = it - slot * per_block;
-      const int seg = rem >> 2, grp = rem & 3;
-      if (q0 + slot >= n_visit) continue; // wave-uniform
-      const int64_t b = base + visit_list[q0 + slot];
-      int8_t zc;
-      bool bright, need;
-      votes(b, true, zc, bright, need);
-      const uint64_t nmask = __ballot(need), bmask = __ballot(bright);
-      const unsigned gmask = (unsigned)(nmask >> (16 * grp)) & 0xffffu;
-      if (gmask == 0) continue; // no chain of this group needs the block: its results are not read
-      const int chain = 16 * grp + ai;
-      const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
-      double s_rs = 0.0, s_lb = 0.0;
-      if (first < covered) { // wave-uniform
-        const float *pf = Xf + (first >> 10) * gf.tile_stride + (first & 1023) + arow_f;
-        const double *pd = Xd + (first >> 9) * gd.tile_stride + (first & 511) + arow_d;
-        const float *bf = thfT + chain;
-        const double *bd = thdT + chain;
-        f32x4 af[4];
-        f64x4 ad[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          af[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          ad[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-        }
-        // column of this lane in k-step j0: j0 + g, clamped to the last real column (its Theta entry is zero)
-        auto col = [&](int j0) { const int j = j0 + ag; return j < d ? j : d - 1; };
-        // two k-steps of rows in flight: buffers A and B alternate, each reloaded right after the MFMAs that
-        // read it have been issued (no copies, so a load has two k-steps of MFMAs to land under)
-        auto loadk = [&](int j0, F4 &f, D2 &a0, D2 &a1) {
-          const int j = col(j0);
-          f = load16<float, false>(pf + (int64_t)j * csf);
-          a0 = load16<double, false>(pd + (int64_t)j * csd);
-          a1 = load16<double, false>(pd + (int64_t)j * csd + 2);
-        };
-        auto mfmak = [&](int j0, const F4 &f, const D2 &a0, const D2 &a1) {
-          const float tb = bf[(j0 + ag) * kBatchCols];
-          const double tdv = bd[(j0 + ag) * kBatchCols];
-#pragma unroll
-          for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[m], tb, af[m], 0, 0, 0);
-          ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], tdv, ad[0], 0, 0, 0);
-          ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], tdv, ad[1], 0, 0, 0);
-          ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], tdv, ad[2], 0, 0, 0);
-          ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], tdv, ad[3], 0, 0, 0);
-        };
-        const int nk = d_pad >> 2;
-        F4 fA, fB;
-        D2 a0A, a1A, a0B, a1B;
-        loadk(0, fA, a0A, a1A);
-        fB = fA, a0B = a0A, a1B = a1A;
-        if (nk > 1) loadk(4, fB, a0B, a1B);
-        int k = 0;
-        for (; k + 2 <= nk; k += 2) {
-          mfmak(4 * k, fA, a0A, a1A);
-          if (k + 2 < nk) loadk(4 * (k + 2), fA, a0A, a1A);
-          mfmak(4 * (k + 1), fB, a0B, a1B);
-          if (k + 3 < nk) loadk(4 * (k + 3), fB, a0B, a1B);
-        }
-        if (k < nk) mfmak(4 * k, fA, a0A, a1A);
-        // element (m, r): segment row 4*(4g + r) + m, chain 16*grp + c
-        if ((gmask >> ai) & 1u) {
-          const bool br = (bmask >> chain) & 1ull;
-#pragma unroll
-          for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              if (first + 4 * (4 * ag + r) + m < covered) {
-                const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, br);
-                s_rs += t.rs;
-                if (br) s_lb += t.lb;
-              }
-            }
-        }
-      }
-      s_rs = lanes_xor_sum_16_32(s_rs);
-      s_lb = lanes_xor_sum_16_32(s_lb);
-      if (ag == 0) {
-        res_rs[slot * segs + seg][chain] = s_rs;
-        res_lb[slot * segs + seg][chain] = s_lb;
-      }
-    }
-    __syncthreads();
-    // ---- resample, accumulate: wave s <-> block b0 + s, lane k <-> chain k ----------------
-    if (wave < R && q0 + wave < n_visit) {
-      const int64_t b = base + visit_list[q0 + wave];
-      int8_t zc;
-      bool bright, need;
-      votes(b, true, zc, bright, need);
-      if (need) {
-        double rs = 0.0, lb = 0.0;
+
+    for (int q = quarter; q < n_visit; q += NW / 4) { // this wave's blocks; no barrier in here
+      const int64_t b = base + visit_list[q];
+      int8_t zc = chain_live ? z[b * kBatchCols + chain] : (int8_t)0;
+      const bool has_rows = (b << p.block_shift) < p.n_rows;
+      const bool bright = zc != 0;
+      const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
+      const bool need = chain_live && has_rows && (bright || re);
+      if (__ballot(need) != 0) { // wave-uniform: some chain of this group needs the block
+        double rs_tot = 0.0, lb_tot = 0.0;
         for (int seg = 0; seg < segs; seg++) {
-          rs += res_rs[wave * segs + seg][lane];
-          lb += res_lb[wave * segs + seg][lane];
+          const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
+          if (first >= covered) break; // wave-uniform
+          const float *pf = Xf + (first >> 10) * gf.tile_stride + (first & 1023) + arow_f;
+          const double *pd = Xd + (first >> 9) * gd.tile_stride + (first & 511) + arow_d;
+          f32x4 af[4];
+          f64x4 ad[4];
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            af[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ad[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+          }
+          // column of this lane in k-step j0: j0 + g, clamped to the last real column (its Theta entry is zero)
+          auto col = [&](int j0) { const int j = j0 + ag; return j < d ? j : d - 1; };
+          // two k-steps of rows in flight: buffers A and B alternate, each reloaded right after the MFMAs that
+          // read it have been issued (no copies, so a load has two k-steps of MFMAs to land under)
+          auto loadk = [&](int j0, F4 &f, D2 &a0, D2 &a1) {
+            const int j = col(j0);
+            f = load16<float, false>(pf + (int64_t)j * csf);
+            a0 = load16<double, false>(pd + (int64_t)j * csd);
+            a1 = load16<double, false>(pd + (int64_t)j * csd + 2);
+          };
+          auto mfmak = [&](int j0, const F4 &f, const D2 &a0, const D2 &a1) {
+            const float tb = bf[(j0 + ag) * kBatchCols];
+            const double tdv = bd[(j0 + ag) * kBatchCols];
+#pragma unroll
+            for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[m], tb, af[m], 0, 0, 0);
+            ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], tdv, ad[0], 0, 0, 0);
+            ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], tdv, ad[1], 0, 0, 0);
+            ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], tdv, ad[2], 0, 0, 0);
+            ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], tdv, ad[3], 0, 0, 0);
+          };
+          const int nk = d_pad >> 2;
+          F4 fA, fB;
+          D2 a0A, a1A, a0B, a1B;
+          loadk(0, fA, a0A, a1A);
+          fB = fA, a0B = a0A, a1B = a1A;
+          if (nk > 1) loadk(4, fB, a0B, a1B);
+          int k = 0;
+          for (; k + 2 <= nk; k += 2) {
+            mfmak(4 * k, fA, a0A, a1A);
+            if (k + 2 < nk) loadk(4 * (k + 2), fA, a0A, a1A);
+            mfmak(4 * (k + 1), fB, a0B, a1B);
+            if (k + 3 < nk) loadk(4 * (k + 3), fB, a0B, a1B);
+          }
+          if (k < nk) mfmak(4 * k, fA, a0A, a1A);
+          // element (m, r): segment row 4*(4g + r) + m, chain 16*grp + c
+          double s_rs = 0.0, s_lb = 0.0;
+          if (need) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                if (first + 4 * (4 * ag + r) + m < covered) {
+                  const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, bright);
+                  s_rs += t.rs;
+                  if (bright) s_lb += t.lb;
+                }
+              }
+          }
+          rs_tot += lanes_xor_sum_16_32(s_rs);
+          lb_tot += lanes_xor_sum_16_32(s_lb);
         }
-        const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
-        const double p_bright = 1.0 - exp(rs);
-        const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
-        if (bright) acc_b += lb;
-        if (zn != zc) z[b * kBatchCols + lane] = zn;
-        zc = zn;
+        if (need) {
+          const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
+          const double p_bright = 1.0 - exp(rs_tot);
+          const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
+          if (bright) acc_b += lb_tot;
+          if (zn != zc && ag == 0) z[b * kBatchCols + chain] = zn;
+          zc = zn;
+        }
       }
       cnt += zc != 0 ? 1 : 0;
     }
-    __syncthreads(); // the next round overwrites the result tables
+    __syncthreads(); // the next window rebuilds the list
   }
-  } // 1024-block window (its last barrier also orders the list's reuse)
-  acc_out[(int64_t)wave_global * kBatchCols + lane] = acc_b;
-  cnt_out[(int64_t)wave_global * kBatchCols + lane] = cnt;
+  // row wave_global of the outputs: this wave's 16 chains, zeros elsewhere (lane l <-> chain l)
+  const bool mine = (lane >> 4) == grp;
+  acc_out[(int64_t)wave_global * kBatchCols + lane] = mine ? acc_b : 0.0;
+  cnt_out[(int64_t)wave_global * kBatchCols + lane] = mine ? cnt : 0;
 }
 
 // grid = K.  res[k*4 + 0] = sum over blocks bright at entry (double)
