@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--data-seed", type=int, default=12345)
     ap.add_argument("--cpu-iters", type=int, default=60, help="MH iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the SP / multi-core / N=100M side measurements")
-    ap.add_argument("--big-rows", type=int, default=100_000_000,
-                    help="rows of the BASELINE configs[3] side measurement (0 = skip)")
+    ap.add_argument("--big-rows", type=int, default=None,
+                    help="rows of the BASELINE configs[3] side measurement (default: 100M beside the N=10M d=64 "
+                         "metric, none for other sizes; 0 = skip)")
     ap.add_argument("--workload", default="mh", choices=["mh", "batched_f32", "batched_f64", "mp_batched"],
                     help="mh (default): BASELINE's metric, the DP MH step at N=10M d=64.  The others time BASELINE "
                          "configs[4] (64 lock-step chains, X.Theta on MFMA, N=10M d=128) on one GPU")
@@ -247,7 +248,9 @@ def main():
     lk.close()
 
     # ---- BASELINE configs[3] beside the metric's size, at every GPU count: N=100M, d=64, the same rows sharded ---
-    if not a.no_extras and (N, d) == (10_000_000, 64) and a.big_rows > 0:
+    if a.big_rows is None:
+        a.big_rows = 100_000_000 if (N, d) == (10_000_000, 64) else 0
+    if not a.no_extras and a.big_rows > 0:
         big = {"rows": a.big_rows, "cols": d}
         try:
             ctx, ok = make_context(a.big_rows)  # 51.2 GB on one GPU, 6.4 GB per GPU on 8

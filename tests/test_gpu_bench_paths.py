@@ -33,3 +33,50 @@ def test_fallback_loop_walks_the_same_chain_as_the_c_sampler():
         _, k2, acc_py = bench.run_host_loop(a, lk, S, np, torch, None, torch.device("cuda", 0), 1, d, K, W, rwsd, barrier)
     assert acc_c == acc_py and 0 < acc_c < K
     assert k1 > 0 and k2 > 0
+
+
+def _bench_line(cmd, env):
+    import json
+    import subprocess
+
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_single_process_line_has_the_contract_fields():
+    env = dict(os.environ)
+    j = _bench_line([sys.executable, "bench.py", "--rows", "400000", "--cols", "16", "--steps", "40", "--warmup", "5",
+                     "--cpu-iters", "6", "--big-rows", "1200000"], env)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 40 and j["dtype"] == "f64" and j["vs_baseline"] is None
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["parity"]["accept_trace_equal"] and c["parity"]["samples_equal"]
+    assert c["parity"]["max_rel_loglik_diff"] <= 1e-10
+    big = j["extra"]["n100m"]
+    assert "error" not in big and big["rows"] == 1200000 and big["it_per_s"] > 0
+
+
+def test_bench_two_rank_flow_on_one_gpu():
+    """The N>1 flow of bench.py (torch.distributed.run launch, row shards, barrier, max over ranks, one JSON line from
+    rank 0, the N=100M-style side run) rehearsed with two ranks on this one GPU.  RCCL refuses two ranks on one device,
+    so the ranks agree on the fallback loop and combine the segment sums through torch.distributed (gloo); the chain is
+    the single-process chain: same acceptance."""
+    env = dict(os.environ)
+    env.update(MHLIK_BENCH_BACKEND="gloo", MHLIK_BENCH_DEVICE="0")
+    common = ["--rows", "400000", "--cols", "16", "--steps", "40", "--warmup", "5", "--cpu-iters", "0"]
+    two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                       "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
+                       "--big-rows", "1200000"] + common, env)
+    one = _bench_line([sys.executable, "bench.py", "--no-extras"] + common, dict(os.environ))
+    assert two["n_gpus"] == 2 and two["config"]["rows_per_gpu"] == 200000
+    assert "fallback host loop" in two["config"]["parallelism"]
+    assert two["acceptance"] == one["acceptance"]
+    big = two["extra"]["n100m"]
+    assert "error" not in big and big["rows_per_gpu"] == 600000 and big["in_library_rccl"] is False
