@@ -7,6 +7,8 @@
 #include <vector>
 #include "batched_lab_v2.hpp"
 #include "batched_lab_v3.hpp"
+#include "batched_lab_f64_ilv.hpp"
+#include <string.h>
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -118,7 +120,20 @@ int main(int argc, char **argv)
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
       printf("f64 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
+    std::vector<double> href((size_t)ntiles * 64);
+#define RUNILV(NKV, EXPV, label) if (d == 4 * NKV) { auto k = lik_batched_f64_ilv_kernel<NKV, EXPV>; \
+      CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
+      std::vector<double> h((size_t)ntiles * 64); CK(hipMemcpy(h.data(), P, sizeof(double) * ntiles * 64, hipMemcpyDeviceToHost)); \
+      size_t bad = 0; for (size_t i = 0; i < h.size(); i++) bad += memcmp(&h[i], &href[i], 8) != 0; \
+      printf("f64 %-28s %.3f ms  %.1f TF   partials differing from the current kernel: %zu of %zu\n", label, ms, flops / ms / 1e9, bad, h.size()); }
     RUN64(0, "current (fast softplus)")
+    CK(hipMemcpy(href.data(), P, sizeof(double) * ntiles * 64, hipMemcpyDeviceToHost));
+    RUNILV(32, 0, "interleaved epilogue")
+    RUNILV(32, 8, "interleaved + sched groups")
+    RUNILV(16, 0, "interleaved epilogue")
+    RUNILV(16, 8, "interleaved + sched groups")
+    RUN64(0, "current (again)")
     RUN64(4, "ocml exp + log epilogue")
     RUN64(1, "no transcendental epilogue")
     RUN64(2, "no global loads in k-loop")
