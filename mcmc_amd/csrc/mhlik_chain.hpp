@@ -104,7 +104,16 @@ __global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int i
     for (int k = threadIdx.x; k < m; k += blockDim.x)
       terms[k] = log_gauss_pdf((double)prop[k0 + k], c.pdf_norm, c.abs_sigma);
     __syncthreads();
-    for (int k = 0; k < m; k++) prior = (T)((double)prior + terms[k]);
+    // eight LDS reads in flight at a time; the additions keep the host loop's order
+    int k = 0;
+    for (; k + 8 <= m; k += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = terms[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) prior = (T)((double)prior + t[u]);
+    }
+    for (; k < m; k++) prior = (T)((double)prior + terms[k]);
   }
 
   if (threadIdx.x == 0) {
