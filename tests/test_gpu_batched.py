@@ -77,6 +77,35 @@ def test_batched_f32_split_is_as_close_to_the_double_dots_as_the_fmaf_chain():
     assert err_split.max() <= 4 * max(err_exact.max(), 5e-8), (err_exact.max(), err_split.max())
 
 
+@pytest.mark.parametrize("N,d,K", [(3000, 384, 64),   # the widest Theta whose three-piece image fits LDS (155 KB, one workgroup per CU)
+                                   (2000, 97, 16), (2000, 97, 17),  # chain-block boundary, ragged last k-block
+                                   (700, 31, 49), (1, 5, 64), (1024, 32, 1), (5000, 160, 33)])
+def test_batched_f32_split_edge_shapes_agree_with_exact_mode(N, d, K):
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(99, N, d)
+    Thf = np.random.default_rng(N + d + K).normal(0, 0.5 / np.sqrt(d), (K, d)).astype(np.float32)
+    want = _oracle_batched(X, Thf.astype(np.float64))
+    with Likelihood(N, d, precision=2) as lk:
+        lk.upload(np.asfortranarray(X.astype(np.float32)))
+        lk.set_batched_f32_mode("exact")
+        exact = lk.loglik_batched(Thf, dtype=np.float32)
+        lk.set_batched_f32_mode("split")
+        split = lk.loglik_batched(Thf, dtype=np.float32)
+    assert np.all(np.abs(split - want) <= 1e-4 * np.abs(want))
+    assert np.all(np.abs(split - exact) <= 2e-6 * np.abs(exact)), np.max(np.abs(split - exact) / np.abs(exact))
+
+
+def test_batched_f32_split_on_an_empty_matrix():
+    from mcmc_amd import Likelihood
+
+    with Likelihood(0, 4, precision=2) as lk:
+        lk.upload(np.zeros((0, 4), dtype=np.float32, order="F"))
+        lk.set_batched_f32_mode("split")
+        assert list(lk.loglik_batched(np.ones((3, 4), dtype=np.float32), dtype=np.float32)) == [0.0, 0.0, 0.0]
+
+
 def test_batched_f32_split_falls_back_when_theta_is_too_wide_for_lds():
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
