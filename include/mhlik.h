@@ -126,6 +126,22 @@ int mhlik_download_f32(mhlik_ctx *ctx, float *X, int64_t ld);
 int mhlik_loglik_f64(mhlik_ctx *ctx, const double *theta, double *out);
 int mhlik_loglik_f32(mhlik_ctx *ctx, const float *theta, float *out);
 
+/* mhlik_loglik_f64 for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO
+ * counterpart in the reference.  Same kernels and the same bits as
+ * mhlik_loglik_f64, but the per-tile partial sums live in a static device
+ * array of MHLIK_NOALLOC_MAX_TILES doubles (2 MiB, held by every GPU the
+ * library runs on until the process ends) instead of the context's buffer,
+ * and the call makes no hipMalloc / hipFree / allocating library call.
+ * Limits (MHLIK_EINVAL / MHLIK_ESTATE with a message otherwise): at most
+ * MHLIK_NOALLOC_MAX_TILES row tiles (512 rows each by default: N <= 134M),
+ * n_cols <= 256 (theta travels in the kernarg), no RCCL communicator.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two contexts driven from two threads) race.  Nothing needs clearing
+ * between calls: every slot the sum reads is written by the same call. */
+#define MHLIK_NOALLOC_MAX_TILES (1 << 18)
+int mhlik_loglik_f64_noalloc(mhlik_ctx *ctx, const double *theta, double *out);
+
 /* K proposals in one pass over X (X.Theta on the matrix cores).  Theta is
  * host row-major [K][n_cols] (chain k contiguous); out[k] = L(Theta[k]).
  * 1 <= K <= MHLIK_MAX_BATCH.  No counterpart in the reference (one chain,

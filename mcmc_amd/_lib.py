@@ -109,6 +109,7 @@ _SIGS = [
     ("mhlik_download_f32", C.c_int, [_P, _P, C.c_int64]),
     ("mhlik_loglik_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("mhlik_loglik_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    ("mhlik_loglik_f64_noalloc", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("mhlik_loglik_batched_f64", C.c_int, [_P, _P, C.c_int32, _P]),
     ("mhlik_loglik_batched_f32", C.c_int, [_P, _P, C.c_int32, _P]),
     ("mhlik_loglik_batched_begin_f64", C.c_int, [_P, _P, C.c_int32]),

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,9 +28,33 @@
 
 using namespace mhlik;
 
+// Scratch of the allocation-free entry point (mhlik_loglik_f64_noalloc): one double per row tile.  Every GPU the
+// library runs on holds its own 2 MiB copy of this array, at its own address, until the process ends.  In host code
+// the NAME is only a stand-in for the symbol: the device address is looked up once per device in mhlik_create
+// (hipGetSymbolAddress, kept in g_scratch_ptr[device]) and only that pointer is ever handed to a kernel.
+#define MHLIK_NOALLOC_MAX_TILES_ (1 << 18)
+static_assert(MHLIK_NOALLOC_MAX_TILES_ == MHLIK_NOALLOC_MAX_TILES, "mhlik.h states the scratch size");
+static __device__ __align__(256) double scratch[MHLIK_NOALLOC_MAX_TILES_];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[kMaxDevices]; // device address of `scratch` on each device, nullptr until looked up
+
+// Once per device, with that device current.
+hipError_t scratch_lookup(int dev)
+{
+  if (dev < 0 || dev >= kMaxDevices) return hipSuccess; // such a device simply has no allocation-free path
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev]) return hipSuccess;
+  void *p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e == hipSuccess) g_scratch_ptr[dev] = (double *)p;
+  return e;
+}
 
 // ------------------------------------------------------------------ RCCL
 // Bound at run time (dlopen) so that single-GPU use needs no librccl and so
@@ -365,9 +390,8 @@ void launch_tile(mhlik_ctx *c, const Store &s, const ThetaArg<T> &th, const T *t
 
 template <typename T>
 int dispatch_tile(mhlik_ctx *c, const Store &s, const ThetaArg<T> &th, const T *theta_g, bool karg, bool want_rowdots,
-                  T *rowdots)
+                  T *rowdots, double *P /* one partial per tile: the context's buffer or the static scratch */)
 {
-  double *P = c->partials;
   if (want_rowdots) {
     // debug path: one fixed shape per R so the tile geometry matches the store
 #define RD(Rv, Uv)                                                                         \
@@ -432,8 +456,9 @@ int wait_published(mhlik_ctx *c, unsigned long long seq)
 
 // Add the per-segment sums of `nvec` results (tile partials -> segment slots
 // -> all shards -> host), leaving out[k] = sum over segments in index order.
-int combine_launch(mhlik_ctx *c, const Store &s, int nvec)
+int combine_launch(mhlik_ctx *c, const Store &s, int nvec, const double *partials = nullptr)
 {
+  if (!partials) partials = c->partials;
   const int nseg = c->nseg, nloc = (int)c->segs.size();
   const bool dist = c->comm != nullptr;
   const int jobs = nloc * nvec;
@@ -446,12 +471,12 @@ int combine_launch(mhlik_ctx *c, const Store &s, int nvec)
   bool published = false;
   double *seg_out = dist ? c->slots_send : c->slots_host_dev;
   if (wide) {
-    hipLaunchKernelGGL(segment_sum_wide_kernel, dim3(jobs), dim3(kSegBlock), 0, c->stream, c->partials,
+    hipLaunchKernelGGL(segment_sum_wide_kernel, dim3(jobs), dim3(kSegBlock), 0, c->stream, partials,
                        (int64_t)s.ntiles, s.segs, nloc, seg_out, nseg);
   } else {
     const int grid = one_group ? 1 : (jobs + kSegWaves - 1) / kSegWaves;
     const bool flag = one_group && !dist;
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, c->partials, (int64_t)s.ntiles,
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid), dim3(kSegBlock), 0, c->stream, partials, (int64_t)s.ntiles,
                        s.segs, nloc, nvec, seg_out, nseg, flag ? c->done_flag_dev : (unsigned long long *)nullptr,
                        flag ? seq : 0ull);
     published = flag;
@@ -495,9 +520,9 @@ int combine_wait(mhlik_ctx *c, double *out)
   return MHLIK_OK;
 }
 
-int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
+int combine(mhlik_ctx *c, const Store &s, int nvec, double *out, const double *partials = nullptr)
 {
-  int rc = combine_launch(c, s, nvec);
+  int rc = combine_launch(c, s, nvec, partials);
   return rc ? rc : combine_wait(c, out);
 }
 
@@ -509,7 +534,10 @@ int combine(mhlik_ctx *c, const Store &s, int nvec, double *out)
       return fail((c), MHLIK_ESTATE, "an evaluation begun with mhlik_*_begin is pending: collect it with its _end call first"); \
   } while (0)
 
-template <typename T> int loglik_impl(mhlik_ctx *c, const T *theta, double *out, T *rowdots_dev)
+// `static_partials`: the allocation-free entry point passes this device's static scratch array; then nothing in
+// here may allocate (wide theta would need the staging buffers, so the caller has rejected it).
+template <typename T> int loglik_impl(mhlik_ctx *c, const T *theta, double *out, T *rowdots_dev,
+                                      double *static_partials = nullptr)
 {
   if (!c) return MHLIK_EINVAL;
   if (!theta || !out) return fail(c, MHLIK_EINVAL, "theta and out must not be NULL");
@@ -535,13 +563,14 @@ template <typename T> int loglik_impl(mhlik_ctx *c, const T *theta, double *out,
   }
   if (c->cfg.timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   if (s.ntiles > 0) {
-    int rc = dispatch_tile<T>(c, s, th, theta_g, karg, rowdots_dev != nullptr, rowdots_dev);
+    int rc = dispatch_tile<T>(c, s, th, theta_g, karg, rowdots_dev != nullptr, rowdots_dev,
+                              static_partials ? static_partials : c->partials);
     if (rc) return rc;
   }
   // the events bracket the streaming kernel alone (the roofline's kernel)
   if (c->cfg.timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   c->last_bytes = c->local_rows * (int64_t)d * (int64_t)sizeof(T);
-  return combine(c, s, 1, out);
+  return combine(c, s, 1, out, static_partials);
 }
 
 template <typename T> int upload_impl(mhlik_ctx *c, const T *X, int64_t ld, int64_t row0)
@@ -690,6 +719,8 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
     }                                                                                       \
   } while (0)
   CREATE_CHK(hipSetDevice(dev));
+  CREATE_CHK(scratch_lookup(dev));
+  c->last_seg_sums.reserve(MHLIK_MAX_SEGMENTS); // so that no evaluation call grows it
   hipDeviceProp_t prop;
   CREATE_CHK(hipGetDeviceProperties(&prop, dev));
   c->compute_units = prop.multiProcessorCount;
@@ -816,6 +847,23 @@ int mhlik_synthetic_beta(uint64_t seed, int32_t n_cols, int32_t *beta)
 }
 
 int mhlik_loglik_f64(mhlik_ctx *c, const double *theta, double *out) { return loglik_impl<double>(c, theta, out, nullptr); }
+
+// The double-precision evaluation with the tile partials in the static scratch array: the same kernels and the same
+// bits as mhlik_loglik_f64, and no hipMalloc / hipFree / allocating routine on the way.
+int mhlik_loglik_f64_noalloc(mhlik_ctx *c, const double *theta, double *out)
+{
+  if (!c) return MHLIK_EINVAL;
+  if (c->comm) return fail(c, MHLIK_ESTATE, "mhlik_loglik_f64_noalloc: single-GPU contexts only (this one has an RCCL communicator)");
+  if (c->cfg.n_cols > kMaxKargCols)
+    return fail(c, MHLIK_EINVAL, "mhlik_loglik_f64_noalloc: n_cols=%d exceeds %d (wider theta needs a staging buffer)",
+                c->cfg.n_cols, kMaxKargCols);
+  if (c->s64.ntiles > MHLIK_NOALLOC_MAX_TILES)
+    return fail(c, MHLIK_EINVAL, "mhlik_loglik_f64_noalloc: %lld row tiles exceed the static scratch (%d tiles of %d rows)",
+                (long long)c->s64.ntiles, MHLIK_NOALLOC_MAX_TILES, c->s64.tile_rows);
+  double *p = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;
+  if (!p) return fail(c, MHLIK_ESTATE, "mhlik_loglik_f64_noalloc: no scratch address for device %d", c->device);
+  return loglik_impl<double>(c, theta, out, nullptr, p);
+}
 
 int mhlik_loglik_f32(mhlik_ctx *c, const float *theta, float *out)
 {

@@ -104,6 +104,15 @@ class Likelihood:
         self._chk(self._lib.mhlik_loglik_f64(self._ctx, _ptr(th), C.byref(out)))
         return out.value
 
+    def loglik_noalloc(self, theta):
+        """mhlik_loglik_f64_noalloc: tile partials in the library's static device array, no allocation in the call."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.shape != (self.n_cols,):
+            raise ValueError("theta must have %d entries" % self.n_cols)
+        out = C.c_double()
+        self._chk(self._lib.mhlik_loglik_f64_noalloc(self._ctx, _ptr(th), C.byref(out)))
+        return out.value
+
     def loglik_f32(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float32)
         if th.shape != (self.n_cols,):
