@@ -46,7 +46,33 @@ def parse():
     ap.add_argument("--f32-mode", default="split", choices=["exact", "split"],
                     help="batched_f32: f32 MFMA (the single-theta kernel's fmaf chain) or three-bf16-piece split (default)")
     ap.add_argument("--resamp-factor", type=int, default=16, help="mp_batched: 1/F of the dark blocks re-examined per step")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="--gpus N>1: if the in-library RCCL communicator cannot be built, time the Python host loop that "
+                         "all-reduces through torch.distributed instead of exiting non-zero (rehearsals on a one-GPU box)")
+    ap.add_argument("--contested-iters", type=int, default=60,
+                    help="MH iterations of the contested-decision parity check of the cpu_baseline leg (0 = skip)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start
+    torch.distributed.run as a CHILD process (this process has not touched the
+    GPU, and never will), relay its output and leave with its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(child.stdout)
+    sys.stdout.flush()
+    raise SystemExit(child.returncode)
 
 
 MFMA_PEAK_TFLOPS = {"batched_f32": 157.3, "batched_f64": 78.6, "mp_batched": 157.3}  # dense, MI355X_MICROARCH.md
@@ -125,6 +151,8 @@ def main():
     a = parse()
     if a.workload != "mh":
         return main_batched(a)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)  # before anything touches the GPU; does not return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -133,19 +161,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
-    # rehearsal knobs for a one-GPU box: every rank on one device, torch.distributed over gloo (the in-library RCCL
-    # communicator cannot be built then -- RCCL refuses two ranks on one GPU -- so the fallback loop runs)
-    backend = os.environ.get("MHLIK_BENCH_BACKEND", "nccl")
+    # torch.distributed is the CONTROL plane only (ships the 128-byte RCCL id, barrier, max of the rank times): gloo by
+    # default, so that the one RCCL communicator on each device is the library's own, the one the data path uses.
+    # MHLIK_BENCH_BACKEND=nccl puts the control plane on RCCL too.  MHLIK_BENCH_DEVICE pins every rank to one device
+    # (rehearsal on a one-GPU box: RCCL refuses two ranks on one GPU, so that needs --allow-fallback).
+    backend = os.environ.get("MHLIK_BENCH_BACKEND", "gloo")
     if "MHLIK_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["MHLIK_BENCH_DEVICE"])
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        print("bench.py: rank %d: only %d GPU(s) visible, sharing device %d (RCCL will refuse several ranks on one "
+              "device)" % (rank, ndev, local_rank % ndev), file=sys.stderr, flush=True)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of torch collectives live
+    allow_fallback = a.allow_fallback or os.environ.get("MHLIK_BENCH_ALLOW_FALLBACK") == "1"
 
     from mcmc_amd import Likelihood, F64, F32
     from mcmc_amd import samplers as S
@@ -165,13 +199,14 @@ def main():
 
     def make_context(rows):
         """The sharded double-precision context of this rank with device-generated data, and whether the
-        in-library RCCL communicator is up on every rank (else the fallback host loop is used)."""
+        in-library RCCL communicator is up on EVERY rank.  If it is not: every rank tears down what it built, and
+        the run ends non-zero -- unless --allow-fallback asked for the torch.distributed host loop."""
         ctx = Likelihood(rows, d, precision=F64, device=local_rank, rank=rank, world=world, timing=True)
         ctx.fill_synthetic(a.data_seed)
         ok = True
         if world > 1:
             # the in-library path: ncclAllReduce on the context's stream, inside the device-resident chain
-            failed = 0
+            failed, why = 0, ""
             try:
                 if os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
                     raise RuntimeError("fallback forced")
@@ -180,12 +215,24 @@ def main():
                     idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
                 dist.broadcast(idt, 0)
                 ctx.comm_init(bytes(idt.cpu().numpy().tobytes()))
+                if ctx.comm_ranks() != world:
+                    raise RuntimeError("communicator has %d ranks, expected %d" % (ctx.comm_ranks(), world))
             except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                why = str(e)
                 print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
                 failed = 1
             t = torch.tensor([failed], dtype=torch.int32, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ok = int(t.item()) == 0
+            if not ok:
+                ctx.comm_destroy()  # a rank that did get a communicator must not all-reduce alone
+                if not allow_fallback:
+                    ctx.close()
+                    dist.barrier()
+                    dist.destroy_process_group()
+                    raise SystemExit("bench.py: rank %d: the in-library RCCL communicator could not be built on every "
+                                     "rank (%s); no number is reported.  --allow-fallback times the torch.distributed "
+                                     "host loop instead." % (rank, why or "another rank failed"))
         elif os.environ.get("MHLIK_BENCH_FORCE_FALLBACK") == "1":
             ok = False
         return ctx, ok
@@ -211,8 +258,10 @@ def main():
     info = lk.info()
     local_bytes = info["local_rows"] * d * 8
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    kernel_name = lk.last_kernel_name()  # the instantiation the timed steps launched
+    rccl_ranks = lk.comm_ranks()
 
-    traffic = pmc_traffic(N, d, info["local_rows"])
+    traffic, traffic_src = pmc_traffic(N, d, info["local_rows"], kernel_name)
     out = {
         "metric": "mh_iterations_per_sec",
         "value": K / elapsed,
@@ -231,10 +280,11 @@ def main():
                    "parallelism": ("rows sharded over %d GPU(s), per-iteration RCCL all-reduce%s" %
                                    (world, "" if in_library_rccl else " through torch.distributed (fallback host loop)"))
                    if world > 1 else "single GPU"},
+        "rccl_ranks": rccl_ranks,
         "likelihood_GBps_whole_job": N * d * 8 / (elapsed / K) / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "lik_tile_kernel<double>", "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": local_bytes},
         "acceptance": n_accepted / K,
     }
@@ -363,24 +413,28 @@ def workload_name(N, d):
             (100_000_000, 64): "BASELINE configs[3]"}.get((N, d), "custom size")
 
 
-def pmc_traffic(N, d, local_rows):
+TRAFFIC_PROFILE = "profiles/r02_bench_pmc_hbm_traffic.json"
+
+
+def pmc_traffic(N, d, local_rows, kernel_name):
     """HBM bytes per launch of the streaming kernel from the committed rocprofv3
-    PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).
-    Counters cannot be read from inside this process; the passes were run on
-    this same command (profiles/r01_bench_pmc_hbm_traffic.json).  null when
-    the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm_traffic.json")
+    PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE;
+    tools/profile_bench.sh).  Counters cannot be read from inside this process,
+    so the figure is only reported when the committed passes were taken on this
+    same workload AND on exactly the kernel instantiation this run just timed
+    (mhlik_last_kernel_name); otherwise null.  Returns (bytes, source file)."""
     try:
-        prof = json.load(open(path))
-    except OSError:
-        return None
+        prof = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+    except (OSError, ValueError):
+        return None, None
     w = prof.get("workload", {})
-    if w.get("rows") != N or w.get("cols") != d or local_rows != N:
-        return None
+    if w.get("rows") != N or w.get("cols") != d or local_rows != N or not kernel_name:
+        return None, None
     for name, k in prof.get("kernels", {}).items():
-        if "lik_tile_kernel<double" in name:
-            return k.get("hbm_bytes_per_launch_corrected")
-    return None
+        # rocprofv3 spells it "void mhlik::lik_tile_kernel<double, 1, 16, true, false, false>(double const*, ...)"
+        if name.split("(")[0].endswith("mhlik::" + kernel_name):
+            return k.get("hbm_bytes_per_launch_corrected"), TRAFFIC_PROFILE
+    return None, None
 
 
 def extras(a, lk, S, np, N, d):
@@ -426,6 +480,7 @@ def cpu_baseline(a, np, N, d, rwsd, lk, S):
         g = S.gpu_sampler(None, a.seed, iters, burn, rwsd, n_rows=N, n_cols=d)
     ct, gt = r["trace"], g["trace"]
     rel = np.abs(ct["lik"] - gt["lik"]) / np.abs(ct["lik"])
+    contested = contested_parity(a, np, O, S, lk, X, N, d, rwsd) if a.contested_iters > 0 else None
     L = O.lib()
     th = np.zeros(d)
     ncores = min(os.cpu_count() or 1, 16)
@@ -440,9 +495,37 @@ def cpu_baseline(a, np, N, d, rwsd, lk, S):
                        "accept_trace_equal": bool(np.array_equal(ct["accept"], gt["accept"])),
                        "samples_equal": bool(np.array_equal(r["samples"], g["samples"])),
                        "max_rel_loglik_diff": float(rel.max()) if len(rel) else None,
-                       "min_decision_margin": float(np.abs(ct["logu"] - ct["ratio"]).min()) if len(rel) else None},
+                       "min_decision_margin": float(np.abs(ct["logu"] - ct["ratio"]).min()) if len(rel) else None,
+                       "note": "this chain starts at theta = 0 with small steps: its decisions are not contested; "
+                               "see `contested`",
+                       "contested": contested},
             "all_cores": {"it_per_s_likelihood_only": 1.0 / mt, "cores": ncores},
             "host_upload": upload}
+
+
+def contested_parity(a, np, O, S, lk, X, N, d, rwsd):
+    """Accept/reject parity where it can fail: the chain is first walked on the
+    GPU and its step size rescaled until a short run's median |log ratio| is a
+    few nats (log u and the ratio are then of the same size, 15-60 % of the
+    proposals accepted), then the SAME start and step size go to the
+    oracle's cpu_sampler and to gpu_sampler (tests/compare_cpu_gpu.c:89-110
+    shape, re-seeded) and the two traces are compared decision by decision."""
+    with S.attached(lk):
+        theta, sd, acc, _ = S.walk_to_contested(N, d, a.seed, np.zeros(d), rwsd)
+        g = S.gpu_sampler(None, a.seed + 7, a.contested_iters, 1, sd, theta0=theta, n_rows=N, n_cols=d)
+    r = O.cpu_sampler(X, a.seed + 7, a.contested_iters, 1, sd, theta0=theta)
+    ct, gt = r["trace"], g["trace"]
+    rel = np.abs(ct["lik"] - gt["lik"]) / np.abs(ct["lik"])
+    margin = np.abs(ct["logu"] - ct["ratio"])
+    worst = int(np.argmin(margin))
+    return {"iterations_compared": int(len(ct)), "rwsd": float(sd), "walk_acceptance": acc,
+            "acceptance": float(np.mean(ct["accept"])),
+            "accept_trace_equal": bool(np.array_equal(ct["accept"], gt["accept"])),
+            "samples_equal": bool(np.array_equal(r["samples"], g["samples"])),
+            "median_abs_ratio": float(np.median(np.abs(ct["ratio"]))),
+            "min_decision_margin": float(margin.min()),
+            "abs_loglik_diff_at_min_margin": float(abs(ct["lik"][worst] - gt["lik"][worst])),
+            "max_rel_loglik_diff": float(rel.max()), "max_abs_loglik_diff": float(np.abs(ct["lik"] - gt["lik"]).max())}
 
 
 def host_upload_rate(X, N, d):

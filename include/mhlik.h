@@ -316,6 +316,11 @@ int mhlik_autocorrelation_f32(mhlik_ctx *ctx, const float *samples, int64_t n, i
 int mhlik_comm_make_id(uint8_t id[MHLIK_COMM_ID_BYTES]);
 int mhlik_comm_init(mhlik_ctx *ctx, const uint8_t id[MHLIK_COMM_ID_BYTES]);
 
+/* Tear the communicator down again (evaluations go back to this rank's rows
+ * only) / number of ranks of the live communicator, 0 when there is none. */
+int mhlik_comm_destroy(mhlik_ctx *ctx);
+int mhlik_comm_ranks(const mhlik_ctx *ctx, int32_t *ranks);
+
 /* Without RCCL (tests, other transports): get this rank's per-segment sums
  * of the LAST evaluation / set the combined ones.  seg_sums has
  * config.segments entries, zero where this rank holds no rows. */
@@ -326,6 +331,12 @@ int mhlik_last_segment_sums(const mhlik_ctx *ctx, double *seg_sums);
 /* Device time of the last likelihood kernel in ms (config.timing != 0) and
  * the algorithmic bytes it read (local rows * n_cols * sizeof(T)). */
 int mhlik_last_kernel_ms(const mhlik_ctx *ctx, float *ms, int64_t *bytes);
+
+/* Which instantiation of the streaming kernel the last evaluation launched,
+ * spelled as rocprofv3 prints it ("lik_tile_kernel<double, 1, 16, true, false,
+ * false>"; "" before the first launch).  bench.py matches it against the
+ * kernel named in the committed counter passes. */
+const char *mhlik_last_kernel_name(const mhlik_ctx *ctx);
 
 /* Geometry actually used (for DESIGN.md / bench reporting). */
 typedef struct mhlik_info {

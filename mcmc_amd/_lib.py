@@ -137,6 +137,9 @@ _SIGS = [
     ("mhlik_autocorrelation_f32", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_float)]),
     ("mhlik_comm_make_id", C.c_int, [_P]),
     ("mhlik_comm_init", C.c_int, [_P, _P]),
+    ("mhlik_comm_destroy", C.c_int, [_P]),
+    ("mhlik_comm_ranks", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("mhlik_last_kernel_name", C.c_char_p, [_P]),
     ("mhlik_last_segment_sums", C.c_int, [_P, _P]),
     ("mhlik_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     ("mhlik_get_info", C.c_int, [_P, C.POINTER(Info)]),

@@ -68,6 +68,7 @@ struct RcclApi {
   int (*GetUniqueId)(ncclUniqueId *) = nullptr;
   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(const ncclComm_t, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool ok = false;
@@ -95,6 +96,7 @@ bool rccl_load(std::string &err)
   RSYM(GetUniqueId, "ncclGetUniqueId")
   RSYM(CommInitRank, "ncclCommInitRank")
   RSYM(CommDestroy, "ncclCommDestroy")
+  RSYM(CommCount, "ncclCommCount")
   RSYM(AllReduce, "ncclAllReduce")
   RSYM(GetErrorString, "ncclGetErrorString")
 #undef RSYM
@@ -203,6 +205,7 @@ struct mhlik_ctx {
 
   float last_ms = 0.f;
   int64_t last_bytes = 0;
+  char last_kernel[96] = ""; // instantiation of the last streaming kernel launched, as a profiler prints it
   std::vector<double> last_seg_sums;
   size_t hbm_bytes = 0;
   std::string err;
@@ -384,6 +387,8 @@ template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
 void launch_tile(mhlik_ctx *c, const Store &s, const ThetaArg<T> &th, const T *theta_g, double *partials, T *rowdots)
 {
   TileGeom g{s.tile_stride, s.col_stride, c->cfg.n_cols};
+  snprintf(c->last_kernel, sizeof c->last_kernel, "lik_tile_kernel<%s, %d, %d, %s, %s, %s>", sizeof(T) == 8 ? "double" : "float",
+           R, U, NT ? "true" : "false", KARG ? "true" : "false", ROWDOTS ? "true" : "false");
   hipLaunchKernelGGL((lik_tile_kernel<T, R, U, NT, KARG, ROWDOTS>), dim3((unsigned)s.ntiles), dim3(kBlock), 0,
                      c->stream, (const T *)s.X, g, s.tile_valid, th, theta_g, partials, rowdots);
 }
@@ -918,6 +923,8 @@ int mhlik_last_kernel_ms(const mhlik_ctx *c, float *ms, int64_t *bytes)
   return MHLIK_OK;
 }
 
+const char *mhlik_last_kernel_name(const mhlik_ctx *c) { return c ? c->last_kernel : ""; }
+
 int mhlik_get_info(const mhlik_ctx *c, mhlik_info *info)
 {
   if (!c || !info) return MHLIK_EINVAL;
@@ -972,6 +979,29 @@ int mhlik_comm_init(mhlik_ctx *c, const uint8_t id[MHLIK_COMM_ID_BYTES])
     c->comm = nullptr;
     return fail(c, MHLIK_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(rc));
   }
+  return MHLIK_OK;
+}
+
+int mhlik_comm_destroy(mhlik_ctx *c)
+{
+  if (!c) return MHLIK_EINVAL;
+  if (!c->comm) return MHLIK_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = g_rccl.ok ? g_rccl.CommDestroy(c->comm) : 0;
+  c->comm = nullptr;
+  if (rc != 0) return fail(c, MHLIK_ECOMM, "ncclCommDestroy: %s", g_rccl.GetErrorString(rc));
+  return MHLIK_OK;
+}
+
+int mhlik_comm_ranks(const mhlik_ctx *c, int32_t *ranks)
+{
+  if (!c || !ranks) return MHLIK_EINVAL;
+  *ranks = 0;
+  if (!c->comm || !g_rccl.ok) return MHLIK_OK;
+  int n = 0;
+  if (g_rccl.CommCount(c->comm, &n) != 0) return MHLIK_ECOMM;
+  *ranks = n;
   return MHLIK_OK;
 }
 

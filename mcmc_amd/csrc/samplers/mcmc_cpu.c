@@ -15,6 +15,7 @@
  */
 #include "mh_core.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static gpu_v_str no_gpu_args(void)
@@ -59,16 +60,26 @@ double acceptance_ratio(mcmc_int_v mclocv, mcmc_int *mcloc, mcmc_str mcin, doubl
 double log_prior(double *sample, mcmc_str mcin) { return log_prior_gpu(sample, mcin); }
 
 /* mcmc_cpu.c:419-445.  The reference reads data.data from host memory on every
- * call; here the matrix has to be in HBM.  An attached context of the right
- * shape is used as is; otherwise the matrix behind data.data is uploaded on
- * the first call and kept until a call arrives with a different pointer or
- * shape (the caller must not change the matrix in place between calls). */
+ * call, so a caller may refill the matrix in place between two calls (the
+ * Nd-sweep loops of tests/gpu_perf.c and tests/large_data_cpu.c do).  Here the
+ * matrix has to be in HBM: an attached context of the right shape is used as
+ * is (the caller then owns the question of what is in it); without one the
+ * matrix behind data.data is uploaded on EVERY call -- never taken from a
+ * previous call, so a stale matrix cannot be evaluated -- into device buffers
+ * that are kept between calls of the same shape and released at exit.  The
+ * upload runs at PCIe speed (0.17 s for 5.12 GB), still faster than one CPU
+ * evaluation of the reference at that size. */
+static mhlik_ctx *g_ll_ctx = NULL;
+static int g_ll_n = 0, g_ll_d = 0, g_ll_atexit = 0;
+
+static void ll_release(void)
+{
+  if (g_ll_ctx) mhlik_destroy(g_ll_ctx);
+  g_ll_ctx = NULL;
+}
+
 double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res)
 {
-  static mhlik_ctx *cached = NULL;
-  static const double *cached_ptr = NULL;
-  static int cached_n = 0, cached_d = 0;
-  int owned = 0;
   mhlik_ctx *lik = NULL;
   mhlik_ctx *att = mcmc_amd_attached_context();
   mhlik_info info;
@@ -76,19 +87,26 @@ double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res
       (info.precision & MHLIK_F64)) {
     lik = att;
   } else {
-    if (cached && (cached_ptr != data.data || cached_n != mcin.Nd || cached_d != mcin.ddata)) {
-      mhlik_destroy(cached);
-      cached = NULL;
-    }
-    if (!cached) {
+    if (g_ll_ctx && (g_ll_n != mcin.Nd || g_ll_d != mcin.ddata)) ll_release();
+    if (!g_ll_ctx) {
+      int owned = 0;
       mcmc_amd_attach_context(NULL);
-      cached = mh_acquire(data, mcin, MHLIK_F64, &owned);
+      g_ll_ctx = mh_acquire(data, mcin, MHLIK_F64, &owned); /* creates and uploads */
       mcmc_amd_attach_context(att);
-      cached_ptr = data.data;
-      cached_n = mcin.Nd;
-      cached_d = mcin.ddata;
+      g_ll_n = mcin.Nd;
+      g_ll_d = mcin.ddata;
+      if (!g_ll_atexit) {
+        atexit(ll_release);
+        g_ll_atexit = 1;
+      }
+    } else {
+      if (!data.data) {
+        fprintf(stderr, "ERROR: data.data is NULL and no context is attached.\n");
+        exit(MHLIK_EINVAL);
+      }
+      MH_CHECK(mhlik_upload_f64(g_ll_ctx, data.data, mcin.Nd, 0), g_ll_ctx);
     }
-    lik = cached;
+    lik = g_ll_ctx;
   }
   out_str tmp;
   memset(&tmp, 0, sizeof tmp);

@@ -277,7 +277,18 @@ class Likelihood:
         buf = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(comm_id)
         self._chk(self._lib.mhlik_comm_init(self._ctx, buf))
 
+    def comm_destroy(self):
+        self._chk(self._lib.mhlik_comm_destroy(self._ctx))
+
+    def comm_ranks(self):
+        n = C.c_int32()
+        self._chk(self._lib.mhlik_comm_ranks(self._ctx, C.byref(n)))
+        return n.value
+
     # -- instrumentation ----------------------------------------------------------
+    def last_kernel_name(self):
+        return (self._lib.mhlik_last_kernel_name(self._ctx) or b"").decode()
+
     def last_kernel(self):
         ms, nbytes = C.c_float(), C.c_int64()
         self._chk(self._lib.mhlik_last_kernel_ms(self._ctx, C.byref(ms), C.byref(nbytes)))

@@ -241,6 +241,34 @@ def mp_sampler(X, seed, Ns, burnin, rwsd, block_rows, blocks, resamp_factor, bou
     return dict(samples=samples, burn=burn, acceptance=res.acceptance, trace=tr, res=res, mp=mp)
 
 
+def walk_to_contested(N, d, seed, theta, rwsd, reps=14, run=300, med_lo=0.5, med_hi=10.0):
+    """Position a chain where accept/reject decisions are contested, on the
+    attached context.  Short gpu_sampler runs continue from where the last one
+    stopped, and after each the random-walk sd is rescaled until the run's
+    median |log ratio| lies in [med_lo, med_hi] with 15-60 % of the proposals
+    accepted: log u and the ratio are then of the same size, so every decision
+    hinges on a log-likelihood difference of a few nats.  (Acceptance alone is
+    not the criterion: while a chain is still climbing, ~40 % of its proposals
+    go uphill and are accepted by hundreds of nats, the rest rejected by as
+    much.)  Returns (theta, rwsd, acceptance, median |ratio|) of the last run.
+    Parity-harness helper; the update is tune_target_a_gpu_v2's multiplicative
+    rule (mcmc_gpu.cu:434-462) driven by the ratio instead of the acceptance."""
+    theta = np.array(theta, dtype=np.float64)
+    acc = med = 0.0
+    for rep in range(reps):
+        r = gpu_sampler(None, seed + 1000 + rep, run, 1, rwsd, theta0=theta, n_rows=N, n_cols=d)
+        theta = r["samples"][-1].copy()
+        acc = float(r["acceptance"])
+        med = float(np.median(np.abs(r["trace"]["ratio"])))
+        if med_lo <= med <= med_hi and 0.15 <= acc <= 0.6:
+            break
+        if med > med_hi or med < med_lo:
+            rwsd *= min(max((3.0 / max(med, 1e-6)) ** 0.7, 0.02), 20.0)  # |ratio| ~ sd while climbing, ~ sd^2 at the mode
+        else:
+            rwsd *= 0.5 if acc < 0.15 else 1.5
+    return theta, rwsd, acc, med
+
+
 def tune_target_a_gpu_v2(X, seed, burnin, rwsd, ratio=0.25, max_reps=40, rng=None, n_rows=None, n_cols=None):
     S = load_samplers()
     if X is not None:

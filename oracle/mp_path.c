@@ -19,19 +19,20 @@
  *   z' = (1 - exp(exponent) <= u_b) ? dark : bright                   [:185-193]
  *   result = sum over blocks bright at entry (double)
  *          + sum over blocks dark at entry (float)                     [:546]
- * u_b comes from mhlik_mp_uniform(seed, call, b) and the float sigmoid from
- * mhlik_sigmoidf_det (mhlik_detmath.h): definitions shared with the device
- * code, because log(L_i - B_i) is the log of a one-float-ulp difference and
- * two different <=1-ulp expf implementations move it by O(1) per row.  The
- * shared expf is checked against libm in tests/test_detmath.py.
+ * u_b = oracle_mp_uniform(seed, call, b) and the float sigmoid is
+ * oracle_sigmoidf_det (oracle/mp_math.h): part of the DEFINITION of the
+ * quantity, because log(L_i - B_i) is the log of a one-float-ulp difference
+ * and two different <=1-ulp expf implementations move it by O(1) per row.
+ * oracle/mp_math.h is the oracle's own statement of that definition; the
+ * product's (mhlik_detmath.h, mhlik_synth.h) shares no code with it, and
+ * tests/test_detmath.py compares the two bit for bit and this one with libm.
  */
 #include "oracle.h"
 
 #include <math.h>
 #include <stdint.h>
 
-#include "mhlik_synth.h"
-#include "mhlik_detmath.h"
+#include "mp_math.h" /* the oracle's own float sigmoid and per-block uniform; no product header in this file */
 
 double oracle_mp_likelihood(const double *Xd, const float *Xf, long N, int d, long lda, const double *theta,
                             int block_rows, int blocks, int resamp_factor, int resamp_choose, uint64_t u_seed,
@@ -54,7 +55,7 @@ double oracle_mp_likelihood(const double *Xd, const float *Xf, long N, int d, lo
     for (long i = r0; i < r1; i++) {
       float ds = 0.0f;
       for (int j = 0; j < d; j++) ds = fmaf((float)theta[j], Xf[(long)j * lda + i], ds);
-      const float sig_s = mhlik_sigmoidf_det(ds);
+      const float sig_s = oracle_sigmoidf_det(ds);
       const double Bd = (double)sig_s - eps;
       if (was_bright || re) {
         double dd = 0.0;
@@ -77,7 +78,7 @@ double oracle_mp_likelihood(const double *Xd, const float *Xf, long N, int d, lo
     else
       red_f += ld;
     if (was_bright || re) {
-      const double u = mhlik_mp_uniform(u_seed, u_call, (uint64_t)b);
+      const double u = oracle_mp_uniform(u_seed, u_call, (uint64_t)b);
       z[b] = ((1.0 - exp(rs)) <= u) ? 0 : 1;
     }
     nb += z[b] != 0;
@@ -103,7 +104,7 @@ double oracle_mp_bound(const double *Xd, const float *Xf, long N, int d, long ld
       dd += theta[j] * Xd[(long)j * lda + i];
     }
     const double L = 1.0 / (1.0 + exp(dd));
-    const double S = (double)mhlik_sigmoidf_det(ds);
+    const double S = (double)oracle_sigmoidf_det(ds);
     s += L;
     if (L - S < mn) mn = L - S;
   }

@@ -66,17 +66,36 @@ def test_bench_single_process_line_has_the_contract_fields():
 def test_bench_two_rank_flow_on_one_gpu():
     """The N>1 flow of bench.py (torch.distributed.run launch, row shards, barrier, max over ranks, one JSON line from
     rank 0, the N=100M-style side run) rehearsed with two ranks on this one GPU.  RCCL refuses two ranks on one device,
-    so the ranks agree on the fallback loop and combine the segment sums through torch.distributed (gloo); the chain is
-    the single-process chain: same acceptance."""
+    so with --allow-fallback the ranks agree on the fallback loop and combine the segment sums through
+    torch.distributed (gloo); the chain is the single-process chain: same acceptance."""
     env = dict(os.environ)
-    env.update(MHLIK_BENCH_BACKEND="gloo", MHLIK_BENCH_DEVICE="0")
+    env.update(MHLIK_BENCH_DEVICE="0")
     common = ["--rows", "400000", "--cols", "16", "--steps", "40", "--warmup", "5", "--cpu-iters", "0"]
     two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                        "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
-                       "--big-rows", "1200000"] + common, env)
+                       "--allow-fallback", "--big-rows", "1200000"] + common, env)
     one = _bench_line([sys.executable, "bench.py", "--no-extras"] + common, dict(os.environ))
     assert two["n_gpus"] == 2 and two["config"]["rows_per_gpu"] == 200000
-    assert "fallback host loop" in two["config"]["parallelism"]
+    assert "fallback host loop" in two["config"]["parallelism"] and two["rccl_ranks"] == 0
     assert two["acceptance"] == one["acceptance"]
+    assert one["rccl_ranks"] == 0 and one["roofline"]["kernel"] == "lik_tile_kernel<double, 1, 16, true, false, false>"
     big = two["extra"]["n100m"]
     assert "error" not in big and big["rows_per_gpu"] == 600000 and big["in_library_rccl"] is False
+
+
+def test_bench_gpus_2_launches_itself_and_fails_loudly_without_rccl():
+    """`python bench.py --gpus 2`, the way the driver calls the 1-GPU run: bench.py starts torch.distributed.run
+    itself as a child process.  On a one-GPU box both ranks share device 0, RCCL refuses that
+    (ncclCommInitRank: invalid usage), and without --allow-fallback the run must END NON-ZERO and print no JSON
+    line -- never a headline number from the fallback loop."""
+    import subprocess
+
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--rows", "200000", "--cols", "16", "--steps", "10", "--warmup",
+           "2", "--cpu-iters", "0", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=280)
+    assert out.returncode != 0, out.stdout + out.stderr[-2000:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout
+    assert "in-library RCCL communicator could not be built" in out.stderr, out.stderr[-3000:]
+    # and the same self-launched command with the explicit flag does report, labelled as the fallback
+    j = _bench_line(cmd + ["--allow-fallback"], dict(os.environ))
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 0 and "fallback host loop" in j["config"]["parallelism"]

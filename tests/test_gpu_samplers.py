@@ -144,6 +144,43 @@ def test_config2_shape_compare_cpu_gpu_trace():
     assert 0.05 < got["acceptance"] < 0.95
 
 
+def test_config2_contested_decisions_trace_equals_cpu_sampler():
+    """BASELINE configs[1] where parity can fail: N=1M, d=16, the chain is first walked on the GPU and its step size
+    rescaled until the median |log ratio| of a run is a few nats (log u and the ratio are then of the same size -- a
+    chain started at theta = 0 with small steps decides everything by hundreds of nats, and so does a chain that is
+    still climbing with large steps), then the same start and step size go to the oracle's
+    cpu_sampler and to gpu_sampler (tests/compare_cpu_gpu.c:89-110 shape, re-seeded; accept test mcmc_cpu.c:57-60)."""
+    from mcmc_amd import Likelihood, samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 1_000_000, 16
+    X = synthetic_host(12345, N, d)
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        with S.attached(lk):
+            sd0 = 2.38 / np.sqrt(d) * 5e-3
+            warm = S.gpu_sampler(None, 11, 2000, 1, sd0, n_rows=N, n_cols=d, trace=False)  # 2000 iterations away from 0
+            theta, sd, acc, walk_med = S.walk_to_contested(N, d, 0, warm["samples"][-1], sd0)
+            assert 0.15 <= acc <= 0.6 and 0.5 <= walk_med <= 10.0, (acc, walk_med, sd)
+            got = S.gpu_sampler(None, 5, 120, 1, sd, theta0=theta, n_rows=N, n_cols=d)
+    ref = O.cpu_sampler(X, 5, 120, 1, sd, theta0=theta)
+    ct, gt = ref["trace"], got["trace"]
+    assert len(ct) == len(gt) == 120
+    med = float(np.median(np.abs(ct["ratio"])))
+    margin = np.abs(ct["logu"] - ct["ratio"])
+    worst = int(np.argmin(margin))
+    rel = np.abs(ct["lik"] - gt["lik"]) / np.abs(ct["lik"])
+    print("contested: sd=%.3g acceptance=%.3f median|ratio|=%.3g min margin=%.3g (|dL| there %.3g) max rel dL=%.3g"
+          % (sd, ct["accept"].mean(), med, margin.min(), abs(ct["lik"][worst] - gt["lik"][worst]), rel.max()))
+    assert 0.05 <= med <= 30.0, "decisions are not contested: median |ratio| = %g" % med
+    assert 0.1 <= ct["accept"].mean() <= 0.7
+    assert np.array_equal(ct["accept"], gt["accept"]), "accept/reject sequence differs"
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert rel.max() <= REL_TOL_DP
+    # the closest call was still decided by far more than the two sums differ
+    assert margin.min() > 100 * np.abs(ct["lik"] - gt["lik"]).max()
+
+
 def test_config1_shape_repeated_runs_share_one_stream():
     """BASELINE configs[0] (tests/multiple_runs_cpu.c:56-71): back-to-back sampler runs on one
     data set with the RNG state carried across runs; GPU and CPU agree run for run."""
@@ -185,9 +222,32 @@ def test_cpu_path_entry_points_run_on_the_gpu_and_match_the_oracle():
     assert np.array_equal(ref["samples"], run["samples"])
     assert np.array_equal(ref["burn"], run["burn"])
     rng = np.random.default_rng(0)
-    for X2 in (X, synthetic_host(7, 5000, 3)):  # a second matrix: the cached context must be replaced
+    for X2 in (X, synthetic_host(7, 5000, 3)):  # a second matrix: the kept buffers must be replaced
         for _ in range(2):
             th = rng.normal(0, 0.2, X2.shape[1])
             want, _ = O.log_likelihood(X2, th)
             got = S.log_likelihood(X2, th)
             assert abs(got - want) <= 1e-10 * abs(want)
+
+
+def test_log_likelihood_sees_a_matrix_refilled_in_place():
+    """The reference's log_likelihood reads data.data on every call (mcmc_cpu.c:419-445), so a caller may refill the
+    matrix in place, or free it and get the same address back (the Nd sweeps of tests/large_data_cpu.c): the product
+    must evaluate what is in host memory NOW, never a copy kept from an earlier call."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d = 40_000, 6
+    X = synthetic_host(21, N, d)
+    th = np.random.default_rng(2).normal(0, 0.3, d)
+    first = S.log_likelihood(X, th)
+    assert abs(first - O.log_likelihood(X, th)[0]) <= 1e-10 * abs(first)
+    X[:] = synthetic_host(22, N, d)  # same pointer, same shape, new contents
+    want, _ = O.log_likelihood(X, th)
+    got = S.log_likelihood(X, th)
+    assert got != first
+    assert abs(got - want) <= 1e-10 * abs(want)
+    X[::7, 1] *= -1.0  # a sparse change no strided sample would be sure to see
+    want, _ = O.log_likelihood(X, th)
+    got = S.log_likelihood(X, th)
+    assert abs(got - want) <= 1e-10 * abs(want)
