@@ -111,3 +111,167 @@ double oracle_mp_bound(const double *Xd, const float *Xf, long N, int d, long ld
   *epsilon = N > 0 ? mn : 0.0;
   return s;
 }
+
+/* ---- the callers: mp_sampler's chain, get_lowerbound, get_blockSz ----------
+ *
+ * Restated from src/mcmc_mp/mcmc_mp.cu: burn_in_metropolis_mp :420-473 and
+ * metropolis_mp :368-418 (chain starts at theta = 1 whatever burn[0] holds,
+ * :430-435; prior N(0, 5^2), :16; accept iff u <= exp(log ratio), :402,:635;
+ * per iteration: d ziggurat draws, gsl_rng_uniform_int for the re-examination
+ * phase inside the likelihood (:504), then one uniform), get_lowerbound
+ * :652-744 (starts at 0, 50000 iterations, keeps the largest per-theta
+ * epsilon), get_blockSz :824-943 with short_run_mp :945-995 (block sizes
+ * 64..1024, ResampFactor = blocks/10, /100, ... while >= 10; 500-iteration
+ * runs from theta = 1, all blocks bright at the start of each).  The
+ * per-block uniforms are oracle_mp_uniform(1234, call, block) with `call`
+ * counting the likelihood evaluations of the current chain from 0.
+ */
+#include <gsl/gsl_randist.h>
+#include <gsl/gsl_rng.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  const double *Xd;
+  const float *Xf;
+  long N, lda;
+  int d;
+  int block_rows, blocks, resamp_factor;
+  double eps;
+  int8_t *z;
+  uint64_t calls;
+  int bright, dark;
+  double last_epsilon; /* lower-bound search */
+  gsl_rng *r;
+} mp_chain;
+
+static double mp_prior5(const double *th, int d)
+{
+  double s = 0.0;
+  for (int j = 0; j < d; j++) s += log(gsl_ran_gaussian_pdf(th[j], 5.0));
+  return s;
+}
+
+static double mp_chain_lik(mp_chain *c, const double *th)
+{
+  const int phase = (int)gsl_rng_uniform_int(c->r, (unsigned long)c->resamp_factor);
+  return oracle_mp_likelihood(c->Xd, c->Xf, c->N, c->d, c->lda, th, c->block_rows, c->blocks, c->resamp_factor, phase,
+                              1234u, c->calls++, c->eps, c->z, &c->bright, &c->dark);
+}
+
+static double mp_chain_bound(mp_chain *c, const double *th)
+{
+  return oracle_mp_bound(c->Xd, c->Xf, c->N, c->d, c->lda, th, &c->last_epsilon);
+}
+
+/* one iteration; `bound` selects the lower-bound search's "likelihood" */
+static int mp_iteration(mp_chain *c, double sd, double *cur, double *prop, double *cpost, int bound,
+                        oracle_trace_rec *tr, long cap, long *ntr)
+{
+  for (int j = 0; j < c->d; j++) prop[j] = cur[j] + gsl_ran_gaussian_ziggurat(c->r, sd);
+  const double pl = bound ? mp_chain_bound(c, prop) : mp_chain_lik(c, prop);
+  const double ppost = mp_prior5(prop, c->d) + pl;
+  const double a = exp(ppost - *cpost);
+  const double u = gsl_rng_uniform(c->r);
+  const int acc = u <= a;
+  if (tr && *ntr < cap) {
+    tr[*ntr].lik = pl;
+    tr[*ntr].ratio = a;
+    tr[*ntr].logu = u;
+    tr[*ntr].accept = acc;
+  }
+  if (ntr) ++*ntr;
+  if (acc) {
+    memcpy(cur, prop, sizeof(double) * (size_t)c->d);
+    *cpost = ppost;
+  }
+  return acc;
+}
+
+/* get_lowerbound (mcmc_mp.cu:652-744); `reps` is LOWERBOUND_REPS (50000, :23) */
+double oracle_get_lowerbound(const double *Xd, const float *Xf, long N, int d, long lda, gsl_rng *r, double rwsd,
+                             int reps, oracle_trace_rec *tr, long cap, long *ntr_out)
+{
+  mp_chain c = {Xd, Xf, N, lda, d, 0, 0, 1, 0.0, NULL, 0, 0, 0, 0.0, r};
+  double *cur = calloc((size_t)d, sizeof(double)), *prop = calloc((size_t)d, sizeof(double));
+  long ntr = 0;
+  double cpost = mp_prior5(cur, d) + mp_chain_bound(&c, cur); /* theta = 0 */
+  double best = c.last_epsilon;
+  for (int i = 1; i < reps; i++) {
+    mp_iteration(&c, rwsd, cur, prop, &cpost, 1, tr, cap, &ntr);
+    if (best < c.last_epsilon) best = c.last_epsilon;
+  }
+  free(cur);
+  free(prop);
+  if (ntr_out) *ntr_out = ntr;
+  return best;
+}
+
+/* The chains get_blockSz times (mcmc_mp.cu:824-943, short_run_mp :945-995), one after the other on one generator.
+ * Which configuration wins is a matter of wall time and not restated; what is: the list of configurations tried
+ * (cfg_out: block size, blocks, ResampFactor triples) and every iteration of every short run (trace). */
+int oracle_get_blockSz_runs(const double *Xd, const float *Xf, long N, int d, long lda, gsl_rng *r, double rwsd,
+                            double bound_eps, int *cfg_out, int cfg_cap, oracle_trace_rec *tr, long cap, long *ntr_out)
+{
+  int ncfg = 0;
+  long ntr = 0;
+  double *cur = calloc((size_t)d, sizeof(double)), *prop = calloc((size_t)d, sizeof(double));
+  for (int bs = 64; bs <= 1024; bs *= 2) {
+    const int blocks = (int)(N / bs);
+    if (blocks < 1) break;
+    int8_t *z = malloc((size_t)blocks);
+    for (int f = blocks / 10; f >= 10; f /= 10) {
+      memset(z, 1, (size_t)blocks);
+      mp_chain c = {Xd, Xf, N, lda, d, bs, blocks, f, bound_eps, z, 0, blocks, 0, 0.0, r};
+      for (int j = 0; j < d; j++) cur[j] = 1.0;
+      double cpost = mp_chain_lik(&c, cur);
+      cpost += mp_prior5(cur, d);
+      for (int i = 1; i < 500; i++) mp_iteration(&c, rwsd, cur, prop, &cpost, 0, tr, cap, &ntr);
+      if (ncfg < cfg_cap) {
+        cfg_out[3 * ncfg] = bs;
+        cfg_out[3 * ncfg + 1] = blocks;
+        cfg_out[3 * ncfg + 2] = f;
+      }
+      ncfg++;
+    }
+    free(z);
+  }
+  free(cur);
+  free(prop);
+  if (ntr_out) *ntr_out = ntr;
+  return ncfg;
+}
+
+/* mp_sampler (mcmc_mp.cu:283-366): burn-in rows 1..burnin-1 then Ns samples. */
+void oracle_mp_sampler(const double *Xd, const float *Xf, long N, int d, long lda, gsl_rng *r, double rwsd,
+                       int block_rows, int blocks, int resamp_factor, double bound_eps, int burnin, int Ns,
+                       double *burn, double *samples, int *accepted_out, int *bright_out, oracle_trace_rec *tr,
+                       long cap, long *ntr_out)
+{
+  int8_t *z = malloc((size_t)(blocks > 0 ? blocks : 1));
+  memset(z, 1, (size_t)(blocks > 0 ? blocks : 1));
+  mp_chain c = {Xd, Xf, N, lda, d, block_rows, blocks, resamp_factor, bound_eps, z, 0, blocks, 0, 0.0, r};
+  double *cur = calloc((size_t)d, sizeof(double)), *prop = calloc((size_t)d, sizeof(double));
+  double cpost = 0.0;
+  long ntr = 0;
+  int accepted = 0;
+  if (burnin != 0) {
+    for (int j = 0; j < d; j++) cur[j] = 1.0;
+    cpost = mp_chain_lik(&c, cur);
+    cpost += mp_prior5(cur, d);
+    for (int i = 1; i < burnin; i++) {
+      mp_iteration(&c, rwsd, cur, prop, &cpost, 0, tr, cap, &ntr);
+      memcpy(burn + (long)i * d, cur, sizeof(double) * (size_t)d);
+    }
+  }
+  for (int i = 0; i < Ns; i++) {
+    accepted += mp_iteration(&c, rwsd, cur, prop, &cpost, 0, tr, cap, &ntr);
+    memcpy(samples + (long)i * d, cur, sizeof(double) * (size_t)d);
+  }
+  if (accepted_out) *accepted_out = accepted;
+  if (bright_out) *bright_out = c.bright;
+  if (ntr_out) *ntr_out = ntr;
+  free(cur);
+  free(prop);
+  free(z);
+}

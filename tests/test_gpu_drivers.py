@@ -1,4 +1,4 @@
-"""bin/mcmc_gpu and bin/mcmc_cpu (the CPU path's driver, run on the GPU) end to end: CSV in, chain CSV out, vs the oracle chain
+"""bin/mcmc_gpu, bin/mcmc_sp, bin/mcmc_mp and bin/mcmc_cpu (the CPU path's driver, run on the GPU) end to end: CSV in, chain CSV out, vs the oracle chain
 (src/mcmc_gpu/gpu_host.c flow; the RNG seed comes from GSL_RNG_SEED like the
 reference's scr/sh_scr/multiple_runs_gpu.sh:5)."""
 import os
@@ -36,3 +36,62 @@ def test_mcmc_gpu_binary_reproduces_oracle_chain(tmp_path, binary, marker):
     assert got.shape == want.shape and np.array_equal(got, want)
     for f in ("burn_out", "norm_raw_out", "norm_burn_out", "mean_out", "circular_autocorrelation"):
         assert os.path.exists(out + f + ".csv")
+
+
+def _run_driver(tmp_path, binary, n, d, Ns, burn, seed, prefix, tune="0"):
+    csv = os.path.join(str(tmp_path), "synthetic.csv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "synthetic_csv.py"), "-sz", str(n), "-dim",
+                           str(d), "-seed", "12345", "-o", csv])
+    out = os.path.join(str(tmp_path), prefix)
+    env = dict(os.environ, GSL_RNG_SEED=str(seed))
+    r = subprocess.run([os.path.join(ROOT, "mcmc_amd", "bin", binary), "-d", "1", "-sz", str(n), "-dim", str(d),
+                        "-samp", str(Ns), "-burn", str(burn), "-lag", "20", "-tune", tune, "-in", csv, "-out", out],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout, out
+
+
+def test_mcmc_sp_binary_runs_the_library_chain(tmp_path):
+    """bin/mcmc_sp (src/mcmc_gpu_sp/gpu_sp_host.c flow): the float chain it writes is the chain sp_sampler walks in
+    process on the same data and seed (float arithmetic: no CPU oracle chain, see test_gpu_mp_callers.py)."""
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    n, d, Ns, burn = 5000, 3, 200, 50
+    stdout, out = _run_driver(tmp_path, "mcmc_sp", n, d, Ns, burn, 7, "sp_")
+    assert "Acceptance Ratio" in stdout
+    got = np.loadtxt(out + "raw_out.csv", delimiter=",")
+    Xf = np.asfortranarray(synthetic_host(12345, n, d).astype(np.float32))
+    ref = S.sp_sampler(Xf, 7, Ns, burn, np.float32(2.38 / np.sqrt(d)), trace=False)
+    want = np.array([[float("%f" % v) for v in row] for row in ref["samples"]])
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert 0 < ref["acceptance"] < 1
+    for f in ("burn_out", "norm_raw_out", "mean_out", "circular_autocorrelation"):
+        assert os.path.exists(out + f + ".csv")
+
+
+def test_mcmc_mp_binary_reproduces_oracle_chain(tmp_path):
+    """bin/mcmc_mp (src/mcmc_mp/mp_host.c:7-80: rwsd 2.313297, the hard-coded bound, 16 blocks of 64 rows,
+    ResampFactor 2) against the oracle's mp_sampler restatement."""
+    import ctypes as C
+
+    from mcmc_amd.likelihood import synthetic_host
+
+    n, d, Ns, burn = 1024, 3, 300, 40
+    stdout, out = _run_driver(tmp_path, "mcmc_mp", n, d, Ns, burn, 3, "mp_")
+    got = np.loadtxt(out + "raw_out.csv", delimiter=",")
+    X = synthetic_host(12345, n, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    L = O.lib()
+    P = C.c_void_p
+    L.oracle_mp_sampler.restype = None
+    L.oracle_mp_sampler.argtypes = [P, P, C.c_long, C.c_int, C.c_long, P, C.c_double, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, C.c_int, C.c_int, P, P, C.POINTER(C.c_int), C.POINTER(C.c_int), P,
+                                    C.c_long, C.POINTER(C.c_long)]
+    samples, burnv = np.zeros((Ns, d)), np.zeros((burn, d))
+    acc, bright, ntr = C.c_int(), C.c_int(), C.c_long()
+    rng = O.Rng(3, L)
+    L.oracle_mp_sampler(O.ptr(X), O.ptr(Xf), n, d, n, rng.r, 2.313297, 64, 16, 2, 0.00000017332527801894315, burn, Ns,
+                        O.ptr(burnv), O.ptr(samples), C.byref(acc), C.byref(bright), None, 0, C.byref(ntr))
+    want = np.array([[float("%f" % v) for v in row] for row in samples])
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -48,6 +48,34 @@ def test_mp_likelihood_sequence_matches_oracle(N, d, block_rows):
             assert abs(got - want) <= 2e-6 * abs(want), (call, got, want)
 
 
+def test_blocks_beyond_the_data_keep_their_indicator_and_add_nothing():
+    """More blocks than the matrix has rows for (the reference's mp_host.c hard-codes 16 x 64 whatever -sz is): a block
+    with no rows contributes nothing and stays bright (oracle/mp_path.c), also right after a larger evaluation left
+    other records in the scratch buffer."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, block_rows, blocks = 5000, 4, 64, 100  # 79 blocks hold rows, 21 hold none
+    X = synthetic_host(17, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    rng = np.random.default_rng(5)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(Xf)
+        lk.mp_reset(64, N // 64)  # fills the record scratch with real records first
+        lk.mp_loglik(rng.normal(0, 0.5, d), 64, N // 64, 2, 0, 1234, 0, 1.7e-7)
+        lk.mp_reset(block_rows, blocks)
+        z = np.ones(blocks, dtype=np.int8)
+        for call in range(4):
+            th = rng.normal(0, 0.5, d)
+            want, wb, wd = _oracle_mp(X, Xf, th, block_rows, blocks, 2, call % 2, 1234, call, 1.7e-7, z)
+            got, gb, gd = lk.mp_loglik(th, block_rows, blocks, 2, call % 2, 1234, call, 1.7e-7)
+            assert (gb, gd) == (wb, wd) and gb >= 21, (call, gb, gd, wb, wd)
+            assert abs(got - want) <= 2e-6 * abs(want), (call, got, want)
+    # (the K-chain entry point takes its indicators per (block, chain) and its sums per tile: empty blocks are covered
+    # by tests/test_gpu_mp_batched.py, N=3000 with 50 blocks of 64)
+
+
 def test_mp_bound_matches_oracle():
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
