@@ -35,6 +35,7 @@
 #ifndef MHLIK_H
 #define MHLIK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -294,6 +295,68 @@ int mhlik_chain_run_f32(mhlik_ctx *ctx, mhlik_chain_batch_f32 *batch);
 /* Read the device-side state back. */
 int mhlik_chain_state_f64(mhlik_ctx *ctx, double *current, double *cposterior);
 int mhlik_chain_state_f32(mhlik_ctx *ctx, float *current, float *cposterior);
+
+/* ---- K lock-step MH chains kept on the device (SURVEY.md section 8 row f3, K chains) ----
+ *
+ * The K-chain twin of mhlik_chain_*: no counterpart in the reference (one
+ * chain, src/mcmc_gpu/mcmc_gpu.cu:101-128).  Chain k is the reference's chain
+ * driven by its own generator: the host draws, per iteration and per chain,
+ * d Gaussians and one uniform in that order (mixed precision: d Gaussians, the
+ * re-examination phase gsl_rng_uniform_int(r_k, ResampFactor), one uniform;
+ * src/mcmc_mp/mcmc_mp.cu:389,504,400), hands a whole batch over, and the device
+ * runs   proposed_k = current_k + increments[i][k]
+ *        L_k = batched likelihood (X.Theta on the matrix cores)
+ *        pposterior_k = sum_j log N(proposed_kj; 0, prior_sd) + L_k
+ *        accept iff log_u[i][k] <= pposterior_k - cposterior_k
+ *        (MHLIK_KCHAIN_MP: iff u[i][k] <= exp(pposterior_k - cposterior_k), mcmc_mp.cu:402)
+ * for i = 0..n-1 back to back with no host round trip.  State is double in
+ * every mode (MHLIK_KCHAIN_F32 rounds the proposals to float for the pass, like
+ * samplers/multichain.c does).  With world > 1 every rank calls with the same
+ * numbers (F64 / F32 modes; mixed precision is single-GPU). */
+enum { MHLIK_KCHAIN_F64 = 1, MHLIK_KCHAIN_F32 = 2, MHLIK_KCHAIN_MP = 3 };
+
+typedef struct mhlik_kchain_mp {
+  int32_t resamp_factor;        /* mp_str.ResampFactor */
+  int32_t reserved;
+  const int32_t *resamp_choose; /* host: the phases; [K] for mhlik_kchain_begin, [n][K] for mhlik_kchain_run */
+  const uint64_t *u_seed;       /* host [K]: seed of chain k's per-block uniforms */
+  uint64_t u_call;              /* call counter of the FIRST evaluation of this call (then +1 per iteration) */
+  double bound_eps;             /* lhoodBound */
+} mhlik_kchain_mp;
+
+typedef struct mhlik_kchain_batch {
+  int64_t n;                 /* iterations in this batch */
+  const double *increments;  /* host [n][K][n_cols] */
+  const double *log_u;       /* host [n][K]: log(u); MHLIK_KCHAIN_MP: u itself */
+  const mhlik_kchain_mp *mp; /* MHLIK_KCHAIN_MP only (block geometry: mhlik_mp_reset_batched) */
+  double *samples;           /* host out [n][K][n_cols]: state after each iteration (NULL: skip) */
+  double *lik;               /* host out [n][K]: L(proposed) (NULL: skip) */
+  double *ratio;             /* host out [n][K]: pposterior - cposterior (MP: its exp) (NULL: skip) */
+  uint8_t *accepted;         /* host out [n][K]: 1 = accepted (NULL: skip) */
+  int32_t *bright_blocks;    /* host out [K], MP: bright blocks after the last iteration (NULL: skip) */
+  int32_t *dark_blocks;      /* host out [K] (NULL: skip) */
+  float kernel_ms;           /* out: mean device time of the sampled batched passes (config.timing) */
+  int32_t kernel_samples;    /* out */
+} mhlik_kchain_batch;
+
+/* Page-locked host memory for the batch arrays (increments, samples, ...):
+ * copies to and from it run at the full PCIe rate and never stage through a
+ * bounce buffer.  Optional -- every entry point takes ordinary memory too. */
+int mhlik_host_alloc(size_t bytes, void **out);
+void mhlik_host_free(void *p);
+
+/* Start K chains at theta0 (host [K][n_cols]): one batched pass,
+ * cposterior[k] = prior + L(theta0_k) (host [K], may be NULL).  mp: the phases,
+ * seeds, counter and bound of that first evaluation (MHLIK_KCHAIN_MP only). */
+int mhlik_kchain_begin(mhlik_ctx *ctx, int32_t mode, int32_t K, const double *theta0, double prior_sd,
+                       const mhlik_kchain_mp *mp, double *cposterior);
+/* Continue from states the caller holds (no likelihood pass). */
+int mhlik_kchain_resume(mhlik_ctx *ctx, int32_t mode, int32_t K, const double *current, const double *cposterior,
+                        double prior_sd);
+/* Run batch->n lock-step iterations; blocks until the outputs are on the host. */
+int mhlik_kchain_run(mhlik_ctx *ctx, mhlik_kchain_batch *batch);
+/* Read the device-side states back: current [K][n_cols], cposterior [K]. */
+int mhlik_kchain_state(mhlik_ctx *ctx, double *current, double *cposterior);
 
 /* ---- chain statistics on the device ---------
  *

@@ -87,6 +87,21 @@ class ChainBatchF32(ChainBatchF64):
     pass
 
 
+class KChainMp(C.Structure):
+    _fields_ = [("resamp_factor", C.c_int32), ("reserved", C.c_int32), ("resamp_choose", C.c_void_p),
+                ("u_seed", C.c_void_p), ("u_call", C.c_uint64), ("bound_eps", C.c_double)]
+
+
+class KChainBatch(C.Structure):
+    _fields_ = [("n", C.c_int64), ("increments", C.c_void_p), ("log_u", C.c_void_p), ("mp", C.POINTER(KChainMp)),
+                ("samples", C.c_void_p), ("lik", C.c_void_p), ("ratio", C.c_void_p), ("accepted", C.c_void_p),
+                ("bright_blocks", C.c_void_p), ("dark_blocks", C.c_void_p), ("kernel_ms", C.c_float),
+                ("kernel_samples", C.c_int32)]
+
+
+KCHAIN_F64, KCHAIN_F32, KCHAIN_MP = 1, 2, 3
+
+
 def lib_path(name="libmhlik.so"):
     return os.path.join(_HERE, "lib", name)
 
@@ -133,6 +148,12 @@ _SIGS = [
     ("mhlik_chain_run_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
     ("mhlik_chain_state_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("mhlik_chain_state_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    ("mhlik_host_alloc", C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    ("mhlik_host_free", None, [_P]),
+    ("mhlik_kchain_begin", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_double, C.POINTER(KChainMp), _P]),
+    ("mhlik_kchain_resume", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_double]),
+    ("mhlik_kchain_run", C.c_int, [_P, C.POINTER(KChainBatch)]),
+    ("mhlik_kchain_state", C.c_int, [_P, _P, _P]),
     ("mhlik_autocorrelation_f64", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("mhlik_autocorrelation_f32", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_float)]),
     ("mhlik_comm_make_id", C.c_int, [_P]),

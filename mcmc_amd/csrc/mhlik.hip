@@ -23,6 +23,7 @@
 #include "mhlik_mp.hpp"
 #include "mhlik_mp_batched.hpp"
 #include "mhlik_chain.hpp"
+#include "mhlik_kchain.hpp"
 #include "mhlik_stats.hpp"
 #include "mhlik_synth.h"
 
@@ -148,6 +149,25 @@ struct ChainHost {
   std::vector<hipEvent_t> ev;
 };
 
+// K lock-step chains on the device (mhlik_kchain.hpp): states + one batch of buffers.
+struct KChainHost {
+  int mode = 0, K = 0;
+  double *cpost = nullptr, *cur = nullptr, *prop = nullptr;
+  int state_K = 0;
+  void *image = nullptr; // Theta in the batched pass's operand order, built on the device from prop
+  size_t image_cap = 0;
+  double *mp_res = nullptr; // [K][4] results of the mixed-precision evaluation (device)
+  double *inc = nullptr, *logu = nullptr, *samples = nullptr, *lik = nullptr, *ratio = nullptr;
+  unsigned char *acc = nullptr;
+  MpbChainArgs *mp_args = nullptr; // [cap_n] phases and seeds of the batch's evaluations
+  int64_t cap_n = 0;
+  int cap_K = 0;
+  double pdf_norm = 0, abs_sigma = 1;
+  double ms_sum = 0; // sampled pass times since begin / resume
+  int ms_n = 0;
+  std::vector<hipEvent_t> ev;
+};
+
 } // namespace
 
 struct mhlik_ctx {
@@ -202,6 +222,7 @@ struct mhlik_ctx {
 
   ncclComm_t comm = nullptr;
   ChainHost chain;
+  KChainHost kchain;
 
   float last_ms = 0.f;
   int64_t last_bytes = 0;
@@ -236,6 +257,7 @@ int fail(mhlik_ctx *c, int code, const char *fmt, ...)
   } while (0)
 
 void chain_free(ChainHost &h);
+void kchain_free(KChainHost &h);
 void mpb_free(mhlik_ctx *c);
 
 struct VariantDef {
@@ -774,6 +796,7 @@ void mhlik_destroy(mhlik_ctx *c)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.ok) g_rccl.CommDestroy(c->comm);
   chain_free(c->chain);
+  kchain_free(c->kchain);
   free_store(c->s64);
   free_store(c->s32);
   if (c->partials) (void)hipFree(c->partials);
@@ -1011,4 +1034,5 @@ int mhlik_comm_ranks(const mhlik_ctx *c, int32_t *ranks)
 #include "mhlik_mp_abi.inc"
 #include "mhlik_mp_batched_abi.inc"
 #include "mhlik_chain_abi.inc"
+#include "mhlik_kchain_abi.inc"
 #include "mhlik_stats_abi.inc"

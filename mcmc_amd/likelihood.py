@@ -251,6 +251,38 @@ class Likelihood:
             self._chk(self._lib.mhlik_chain_state_f32(self._ctx, _ptr(cur), C.byref(cp)))
         return cur, cp.value
 
+    # ---- K lock-step chains kept on the device (mhlik_kchain_*) ----
+    def kchain_begin(self, theta0, prior_sd, mode=1):
+        """Start K chains at theta0 [K, d] (mode 1 = f64, 2 = f32 pass); returns cposterior[K]."""
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        K = th.shape[0]
+        cp = np.empty(K)
+        self._chk(self._lib.mhlik_kchain_begin(self._ctx, int(mode), K, _ptr(th), float(prior_sd), None, _ptr(cp)))
+        return cp
+
+    def kchain_resume(self, current, cposterior, prior_sd, mode=1):
+        cur = np.ascontiguousarray(current, dtype=np.float64)
+        cp = np.ascontiguousarray(cposterior, dtype=np.float64)
+        self._chk(self._lib.mhlik_kchain_resume(self._ctx, int(mode), cur.shape[0], _ptr(cur), _ptr(cp), float(prior_sd)))
+
+    def kchain_run(self, increments, log_u):
+        """increments [n, K, d], log_u [n, K]; returns dict(samples, lik, ratio, accepted, kernel_ms)."""
+        inc = np.ascontiguousarray(increments, dtype=np.float64)
+        lu = np.ascontiguousarray(log_u, dtype=np.float64)
+        n, K, d = inc.shape
+        samples = np.empty((n, K, d))
+        lik, ratio, acc = np.empty((n, K)), np.empty((n, K)), np.empty((n, K), dtype=np.uint8)
+        b = L.KChainBatch(n=n, increments=_ptr(inc).value, log_u=_ptr(lu).value, samples=_ptr(samples).value,
+                          lik=_ptr(lik).value, ratio=_ptr(ratio).value, accepted=_ptr(acc).value)
+        self._chk(self._lib.mhlik_kchain_run(self._ctx, C.byref(b)))
+        return dict(samples=samples, lik=lik, ratio=ratio, accepted=acc, kernel_ms=b.kernel_ms,
+                    kernel_samples=b.kernel_samples)
+
+    def kchain_state(self, K):
+        cur, cp = np.empty((K, self.n_cols)), np.empty(K)
+        self._chk(self._lib.mhlik_kchain_state(self._ctx, _ptr(cur), _ptr(cp)))
+        return cur, cp
+
     # -- chain statistics ---------------------------------------------------------
     def autocorrelation(self, samples, lags, dtype=np.float64):
         """circular_autocorrelation on the device: returns (out_v[lags], sum of out_v[1:])."""
