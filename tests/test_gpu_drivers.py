@@ -95,3 +95,41 @@ def test_mcmc_mp_binary_reproduces_oracle_chain(tmp_path):
                         O.ptr(burnv), O.ptr(samples), C.byref(acc), C.byref(bright), None, 0, C.byref(ntr))
     want = np.array([[float("%f" % v) for v in row] for row in samples])
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_compare_harnesses_write_their_rows(tmp_path):
+    """bin/compare_gpu_sp and bin/compare_cpu_gpu (tests/compare_gpu_sp.c:95-123, tests/compare_cpu_gpu.c:86-110 of the
+    reference: tune, run both samplers, one CSV row of times + ESS each).  With -reseed 1 (ours) the CPU-path and
+    GPU-path samplers of compare_cpu_gpu walk the same chain: identical samples, identical ESS."""
+    n, d, Ns, burn = 6000, 4, 1500, 200
+    csv = os.path.join(str(tmp_path), "synthetic.csv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "synthetic_csv.py"), "-sz", str(n), "-dim",
+                           str(d), "-seed", "12345", "-o", csv])
+    env = dict(os.environ, GSL_RNG_SEED="5")
+    common = ["-d", "3", "-sz", str(n), "-dim", str(d), "-samp", str(Ns), "-burn", str(burn), "-lag", "100", "-tune", "1",
+              "-in", csv]
+
+    def rows(path):
+        return [[float(x) for x in ln.split(",")] for ln in open(path) if ln.strip()]
+
+    out = os.path.join(str(tmp_path), "cg_")
+    r = subprocess.run([os.path.join(ROOT, "mcmc_amd", "bin", "compare_cpu_gpu")] + common + ["-out", out, "-reseed", "1"],
+                       capture_output=True, text=True, env=env, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "identical sample for sample" in r.stdout
+    cpu, gpu = rows(out + "cpu.csv"), rows(out + "gpu.csv")
+    assert len(cpu) == len(gpu) == 1 and cpu[0][:2] == gpu[0][:2] == [d, n]
+    assert cpu[0][5] == gpu[0][5] > 0  # the same chain: the same ESS
+    assert all(v > 0 for v in cpu[0][2:5] + gpu[0][2:5])
+
+    out = os.path.join(str(tmp_path), "gs_")
+    r = subprocess.run([os.path.join(ROOT, "mcmc_amd", "bin", "compare_gpu_sp")] + common + ["-out", out],
+                       capture_output=True, text=True, env=env, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    sp, gpu = rows(out + "sp.csv"), rows(out + "gpu.csv")
+    assert len(sp) == len(gpu) == 1 and sp[0][:2] == gpu[0][:2] == [d, n]
+    assert sp[0][5] > 0 and gpu[0][5] > 0 and 0.2 < sp[0][5] / gpu[0][5] < 5.0  # both chains mix; float vs double
+    # a second invocation appends (the reference opens its files with "a")
+    subprocess.run([os.path.join(ROOT, "mcmc_amd", "bin", "compare_gpu_sp")] + common + ["-out", out], capture_output=True,
+                   text=True, env=env, timeout=200)
+    assert len(rows(out + "sp.csv")) == 2
