@@ -81,7 +81,10 @@ typedef struct mhlik_config {
   int32_t layout;    /* MHLIK_LAYOUT_* */
   int32_t variant;   /* kernel variant; 0 = default (tuning knob) */
   int32_t timing;    /* !=0: bracket the likelihood kernel with events */
-  int32_t reserved[6];
+  int32_t segment_align; /* 0/1: segments of ceil(N/segments) rows.  > 1: that count rounded up to a multiple of this
+                            (trailing segments may then be empty).  Mixed precision over several segments / GPUs
+                            needs a multiple of 1024, so that data blocks and tiles never straddle a shard. */
+  int32_t reserved[5];
 } mhlik_config;
 
 /* Create a context on config->device.  Allocates nothing large until data is
@@ -201,6 +204,18 @@ int mhlik_mp_loglik(mhlik_ctx *ctx, const mhlik_mp_state *st, const double *thet
  * extreme of epsilon_i = sigma_D - sigma_S over all rows. */
 int mhlik_mp_bound(mhlik_ctx *ctx, const double *theta, double *sum_lb, double *epsilon);
 
+/* Row shards (no counterpart: the reference is single-GPU, mcmc_mp.cu:286).
+ * mhlik_mp_loglik / mhlik_mp_bound work on contexts with several segments and
+ * world > 1 when config.segment_align is a multiple of 1024: every rank calls
+ * with the same arguments, each evaluates the data blocks of its own rows,
+ * the per-segment sums (double sum, float sum, bright count) are all-reduced
+ * like the DP path's and added in segment order -- the same bits for every
+ * world.  Without a communicator (other transports, tests) the call returns
+ * this rank's share and mhlik_mp_last_slots hands out its 3*segments slots
+ * [double sums | float sums | bright counts] (mhlik_mp_bound: [sums | minima])
+ * to be summed over the ranks by the caller. */
+int mhlik_mp_last_slots(const mhlik_ctx *ctx, double *slots);
+
 /* ---- mixed precision, K lock-step chains (BASELINE.json config 5) -------
  *
  * No counterpart in the reference (one chain per mp_likelihood call,
@@ -211,7 +226,8 @@ int mhlik_mp_bound(mhlik_ctx *ctx, const double *theta, double *sum_lb, double *
  * float dots of ALL rows and chains (the reference's cublasSgemv over the
  * whole matrix, :515) run as one X.Theta pass on the matrix cores; double
  * arithmetic touches only the (block, chain) pairs that are bright or
- * re-examined in this call.  Needs segments=1, world=1, both matrices. */
+ * re-examined in this call.  Needs segments=1, world=1 (the K-chain pass is
+ * single-GPU; the single-chain path above shards), both matrices. */
 typedef struct mhlik_mp_batch {
   int32_t block_rows;           /* mp_str.dataBlockSz */
   int32_t blocks;               /* mp_str.dataBlocks */

@@ -179,6 +179,7 @@ struct mhlik_ctx {
   int nseg = 8;
   std::vector<Segment> segs; // local
   int64_t local_begin = 0, local_rows = 0;
+  int64_t seg_rows = 0; // rows per fixed segment (the last non-empty one may hold fewer)
   int layout = MHLIK_LAYOUT_TILED;
   Store s64, s32;
 
@@ -208,6 +209,7 @@ struct mhlik_ctx {
   int32_t mp_blocks = 0, mp_block_rows = 0;
   double *mp_out = nullptr; // device scratch
   size_t mp_out_cap = 0;
+  std::vector<double> mp_last_slots; // per-segment sums of the last mixed-precision evaluation
   // mixed precision, K chains (mhlik_mp_batched.hpp)
   int8_t *mpb_z = nullptr;      // [blocks][64]
   int32_t mpb_blocks = 0, mpb_block_rows = 0, mpb_K = 0;
@@ -714,6 +716,7 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
                 MHLIK_MAX_SEGMENTS, world);
   if (cfg->variant < 0 || cfg->variant >= kNumVariants) return fail(nullptr, MHLIK_EINVAL, "unknown variant %d", cfg->variant);
   if (cfg->layout < 0 || cfg->layout > MHLIK_LAYOUT_COLMAJOR) return fail(nullptr, MHLIK_EINVAL, "unknown layout %d", cfg->layout);
+  if (cfg->segment_align < 0) return fail(nullptr, MHLIK_EINVAL, "segment_align must be >= 0");
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -748,6 +751,7 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
   CREATE_CHK(hipSetDevice(dev));
   CREATE_CHK(scratch_lookup(dev));
   c->last_seg_sums.reserve(MHLIK_MAX_SEGMENTS); // so that no evaluation call grows it
+  c->mp_last_slots.reserve(3 * MHLIK_MAX_SEGMENTS);
   hipDeviceProp_t prop;
   CREATE_CHK(hipGetDeviceProperties(&prop, dev));
   c->compute_units = prop.multiProcessorCount;
@@ -759,7 +763,9 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
 
   // fixed row segments: the summation is grouped by them whatever the GPU count
   const int64_t N = cfg->n_rows;
-  const int64_t seg_rows = (N + nseg - 1) / nseg;
+  int64_t seg_rows = (N + nseg - 1) / nseg;
+  if (cfg->segment_align > 1) seg_rows = (seg_rows + cfg->segment_align - 1) / cfg->segment_align * cfg->segment_align;
+  c->seg_rows = seg_rows;
   const int per = nseg / world;
   for (int g = cfg->rank * per; g < (cfg->rank + 1) * per; g++) {
     Segment sg;

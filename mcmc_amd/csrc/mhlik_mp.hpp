@@ -34,7 +34,8 @@ struct MpParams {
   int32_t resamp_choose;
   uint64_t u_seed, u_call;
   double eps;
-  int64_t n_rows; // rows that exist
+  int64_t n_rows;   // rows that exist (global)
+  int64_t row_base; // global row of this shard's first tile (a multiple of 1024)
 };
 
 // per-block uniforms: mhlik_mp_uniform in mhlik_synth.h (stands in for the
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void mp_tile_kernel(const float *__restrict
   const int d = gf.d;
   const int64_t tile = blockIdx.x;
   const int lane_row = threadIdx.x * 4;                // first of this lane's 4 rows in the tile
-  const int64_t row0 = tile * kMpTileRows + lane_row;  // global row
+  const int64_t row0 = p.row_base + tile * kMpTileRows + lane_row;  // global row
   const int64_t covered = (int64_t)p.blocks * p.block_rows < p.n_rows ? (int64_t)p.blocks * p.block_rows : p.n_rows;
   const int64_t b = row0 / p.block_rows;               // this lane's data block
   const bool lane_live = row0 < covered;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void mp_tile_kernel(const float *__restrict
   const int rows_per_block = p.block_rows / 64;    // DPP rows per data block: 1..16
   const int blocks_per_tile = 16 / rows_per_block; // data blocks in this tile
   if ((int)threadIdx.x < blocks_per_tile) {
-    const int64_t blk = tile * blocks_per_tile + threadIdx.x;
+    const int64_t blk = p.row_base / p.block_rows + tile * blocks_per_tile + threadIdx.x; // global block
     if (blk < p.blocks && blk * p.block_rows < p.n_rows) {
       float ld = 0.f;
       double lb = 0.0, rs = 0.0;
@@ -234,16 +235,21 @@ __global__ __launch_bounds__(kBlock) void mp_tile_kernel(const float *__restrict
 //   res[0] = red_d (double sum over blocks bright at entry)
 //   res[1] = red_f (float sum over blocks dark at entry)
 //   res[2] = bright count after resampling, res[3] = dark count
-constexpr int kMpReduceGroups = 256;
+constexpr int kMpReduceGroups = 256; // groups over ALL segments: a segment gets kMpReduceGroups / segments of them
 
+// grid = G groups of one row segment, whose blocks are [lo_blk, hi_blk): group j sums the records of its contiguous
+// run.  part[j], part[G + j], part[2G + j] = double sum / float sum / bright count.  The shape depends on the
+// segment's block range and on G alone, never on which GPU holds the segment.
 __global__ __launch_bounds__(kBlock) void mp_reduce_kernel(const MpBlockOut *__restrict__ out,
-                                                           const int8_t *__restrict__ z, int32_t blocks,
-                                                           double *__restrict__ part /* [3][kMpReduceGroups] */)
+                                                           const int8_t *__restrict__ z, int32_t lo_blk, int32_t hi_blk,
+                                                           double *__restrict__ part /* [3][G] */)
 {
   __shared__ double lds[kBlock / kWave];
-  const int per = (blocks + kMpReduceGroups - 1) / kMpReduceGroups;
-  const int lo = blockIdx.x * per;
-  const int hi = lo + per < blocks ? lo + per : blocks;
+  const int G = gridDim.x;
+  const int blocks = hi_blk - lo_blk;
+  const int per = (blocks + G - 1) / G;
+  const int lo = lo_blk + blockIdx.x * per;
+  const int hi = lo + per < hi_blk ? lo + per : hi_blk;
   double sd = 0.0, nb = 0.0;
   float sf = 0.f;
   for (int b0 = lo + (int)threadIdx.x; b0 < hi; b0 += kBlock * 8) {
@@ -277,26 +283,30 @@ __global__ __launch_bounds__(kBlock) void mp_reduce_kernel(const MpBlockOut *__r
   double tb = block_sum(nb, lds);
   if (threadIdx.x == 0) {
     part[blockIdx.x] = t;
-    part[kMpReduceGroups + blockIdx.x] = tf;
-    part[2 * kMpReduceGroups + blockIdx.x] = tb;
+    part[G + blockIdx.x] = tf;
+    part[2 * G + blockIdx.x] = tb;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void mp_reduce_final_kernel(const double *__restrict__ part, int32_t blocks,
-                                                                 double *__restrict__ res)
+// grid = local segments.  Workgroup s adds the G group partials of local segment s (part + s*3*G) and stores the
+// segment's three sums into the slot vector: slots[global], slots[nseg + global], slots[2*nseg + global].
+__global__ __launch_bounds__(kBlock) void mp_reduce_final_kernel(const double *__restrict__ part, int G,
+                                                                 const int32_t *__restrict__ seg_global, int nseg,
+                                                                 double *__restrict__ slots)
 {
   __shared__ double lds[kBlock / kWave];
-  static_assert(kMpReduceGroups == kBlock, "one partial per thread");
-  double t = block_sum(part[threadIdx.x], lds);
+  const double *p = part + (int64_t)blockIdx.x * 3 * G;
+  const bool has = (int)threadIdx.x < G;
+  double t = block_sum(has ? p[threadIdx.x] : 0.0, lds);
   __syncthreads();
-  double tf = block_sum(part[kMpReduceGroups + threadIdx.x], lds);
+  double tf = block_sum(has ? p[G + threadIdx.x] : 0.0, lds);
   __syncthreads();
-  double tb = block_sum(part[2 * kMpReduceGroups + threadIdx.x], lds);
+  double tb = block_sum(has ? p[2 * G + threadIdx.x] : 0.0, lds);
   if (threadIdx.x == 0) {
-    res[0] = t;
-    res[1] = (double)(float)tf; // rounded to float once
-    res[2] = tb;
-    res[3] = (double)blocks - tb;
+    const int g = seg_global[blockIdx.x];
+    slots[g] = t;
+    slots[nseg + g] = tf;
+    slots[2 * nseg + g] = tb;
   }
 }
 
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void mp_reduce_final_kernel(const double *_
 // the minimum of eps_i = sigma_D - sigma_S.
 __global__ __launch_bounds__(kBlock) void mp_bound_kernel(const float *__restrict__ Xf, TileGeom gf,
                                                           const double *__restrict__ Xd, TileGeom gd,
-                                                          ThetaArg<double> theta, int64_t n_rows,
+                                                          ThetaArg<double> theta, int64_t n_rows, int64_t row_base,
                                                           double *__restrict__ tile_sum,
                                                           double *__restrict__ tile_min)
 {
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void mp_bound_kernel(const float *__restric
   const int d = gf.d;
   const int64_t tile = blockIdx.x;
   const int lane_row = threadIdx.x * 4;
-  const int64_t row0 = tile * kMpTileRows + lane_row;
+  const int64_t row0 = row_base + tile * kMpTileRows + lane_row; // global row
   float accf[4] = {0.f, 0.f, 0.f, 0.f};
   double accd[4] = {0.0, 0.0, 0.0, 0.0};
   const float *tf = Xf + tile * gf.tile_stride + lane_row;
@@ -355,25 +365,28 @@ __global__ __launch_bounds__(kBlock) void mp_bound_kernel(const float *__restric
   }
 }
 
-// Single workgroup: total of the tile sums and minimum of the tile minima.
+// grid = local segments: total of the segment's tile sums and minimum of its tile minima, stored at
+// slots[global] and slots[nseg + global] (a segment without rows: 0 and +inf).
 __global__ __launch_bounds__(kBlock) void mp_bound_final_kernel(const double *__restrict__ tile_sum,
-                                                                const double *__restrict__ tile_min, int64_t tiles,
-                                                                double *__restrict__ res)
+                                                                const double *__restrict__ tile_min,
+                                                                const SegDesc *__restrict__ segs, int nseg,
+                                                                double *__restrict__ slots)
 {
   __shared__ double lds[kBlock / kWave];
   __shared__ double lds_min[kBlock / kWave];
+  const SegDesc sd = segs[blockIdx.x];
   double s = 0.0, mn = __builtin_inf();
-  for (int64_t t = threadIdx.x; t < tiles; t += kBlock) {
-    s += tile_sum[t];
-    mn = fmin(mn, tile_min[t]);
+  for (int64_t t = threadIdx.x; t < sd.tile_count; t += kBlock) {
+    s += tile_sum[sd.tile_begin + t];
+    mn = fmin(mn, tile_min[sd.tile_begin + t]);
   }
   s = block_sum(s, lds);
   for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off));
   if ((threadIdx.x & 63) == 0) lds_min[threadIdx.x >> 6] = mn;
   __syncthreads();
   if (threadIdx.x == 0) {
-    res[0] = s;
-    res[1] = fmin(fmin(lds_min[0], lds_min[1]), fmin(lds_min[2], lds_min[3]));
+    slots[sd.global_index] = s;
+    slots[nseg + sd.global_index] = fmin(fmin(lds_min[0], lds_min[1]), fmin(lds_min[2], lds_min[3]));
   }
 }
 

@@ -19,9 +19,11 @@ Two transports:
 import numpy as np
 
 
-def segment_rows(n_rows, segments=8):
-    """[(begin, rows)] of the fixed row segments (same rule as mhlik_create)."""
+def segment_rows(n_rows, segments=8, align=1):
+    """[(begin, rows)] of the fixed row segments (same rule as mhlik_create; `align` = config.segment_align)."""
     per = (n_rows + segments - 1) // segments
+    if align > 1:
+        per = (per + align - 1) // align * align
     out = []
     for g in range(segments):
         b = min(g * per, n_rows)
@@ -30,13 +32,13 @@ def segment_rows(n_rows, segments=8):
     return out
 
 
-def shard_rows(n_rows, rank, world, segments=8):
+def shard_rows(n_rows, rank, world, segments=8, align=1):
     """(first global row, row count, [segment indices]) held by `rank`."""
     if segments % world != 0:
         raise ValueError("segments=%d must be a multiple of world=%d" % (segments, world))
     per = segments // world
     segs = list(range(rank * per, (rank + 1) * per))
-    rows = segment_rows(n_rows, segments)
+    rows = segment_rows(n_rows, segments, align)
     begin = rows[segs[0]][0]
     count = sum(rows[g][1] for g in segs)
     return begin, count, segs
@@ -64,7 +66,8 @@ class ShardedLikelihood:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.segments = segments
         self.transport = transport if self.world > 1 else "none"
-        self.begin, self.rows, self.segs = shard_rows(n_rows, self.rank, self.world, segments)
+        self.begin, self.rows, self.segs = shard_rows(n_rows, self.rank, self.world, segments,
+                                                      int(kw.get("segment_align", 0) or 1))
         if local_factory is None:
             from .likelihood import Likelihood
 
@@ -98,6 +101,25 @@ class ShardedLikelihood:
             return v  # already the sum over all shards
         slots = self._reduce_slots(self.local.segment_sums())
         return combine_segment_sums(slots)
+
+    # -- mixed precision over the shards (needs segment_align = a multiple of 1024) --
+    def mp_reset(self, block_rows, blocks):
+        self.local.mp_reset(block_rows, blocks)
+
+    def mp_loglik(self, theta, block_rows, blocks, resamp_factor, resamp_choose, u_seed, u_call, bound_eps):
+        """(value, bright blocks, dark blocks) over all shards: every rank evaluates the data blocks of its own rows;
+        the per-segment sums are all-reduced and added in segment order (mhlik_mp_loglik's own combination)."""
+        v, nb, nd = self.local.mp_loglik(theta, block_rows, blocks, resamp_factor, resamp_choose, u_seed, u_call, bound_eps)
+        if self.transport in ("rccl", "none"):
+            return v, nb, nd
+        slots = self._reduce_slots(self.local.mp_last_slots())
+        S = self.segments
+        red_d = red_f = bright = 0.0
+        for g in range(S):
+            red_d += float(slots[g])
+            red_f += float(slots[S + g])
+            bright += float(slots[2 * S + g])
+        return red_d + float(np.float32(red_f)), int(bright), int(blocks) - int(bright)
 
     def close(self):
         self.local.close()

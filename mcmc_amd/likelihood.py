@@ -22,13 +22,14 @@ def _ptr(a):
 
 class Likelihood:
     def __init__(self, n_rows, n_cols, precision=F64, device=-1, rank=0, world=1, segments=0,
-                 layout=LAYOUT_DEFAULT, variant=0, timing=False):
+                 layout=LAYOUT_DEFAULT, variant=0, timing=False, segment_align=0):
         self._lib = L.load_mhlik()
         self._ctx = C.c_void_p()
         cfg = L.Config()
         cfg.n_rows, cfg.n_cols, cfg.precision, cfg.device = int(n_rows), int(n_cols), int(precision), int(device)
         cfg.rank, cfg.world, cfg.segments = int(rank), int(world), int(segments)
         cfg.layout, cfg.variant, cfg.timing = int(layout), int(variant), int(bool(timing))
+        cfg.segment_align = int(segment_align)
         rc = self._lib.mhlik_create(C.byref(cfg), C.byref(self._ctx))
         if rc != 0:
             raise L.MhlikError(rc, (self._lib.mhlik_last_error(None) or b"").decode())
@@ -173,6 +174,12 @@ class Likelihood:
         out, nb, nd = C.c_double(), C.c_int32(), C.c_int32()
         self._chk(self._lib.mhlik_mp_loglik(self._ctx, C.byref(st), _ptr(th), C.byref(out), C.byref(nb), C.byref(nd)))
         return out.value, nb.value, nd.value
+
+    def mp_last_slots(self):
+        """[double sums | float sums | bright counts] per segment of the last mp_loglik (mp_bound: [sums | minima])."""
+        out = np.zeros(3 * self.segments, dtype=np.float64)
+        self._chk(self._lib.mhlik_mp_last_slots(self._ctx, _ptr(out)))
+        return out
 
     def mp_bound(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)

@@ -84,3 +84,108 @@ def test_rccl_path_with_one_rank(monkeypatch):
         lk.comm_init(Likelihood.make_comm_id())
         assert [lk.loglik(t) for t in ths] == plain
         assert np.array_equal(lk.loglik_batched(np.array(ths)), plain_b)
+
+
+# ---- mixed precision over row shards ------------------------------------------------------------------------------
+MP_N, MP_D, MP_BLOCK, MP_RF, MP_EPS = 300_007, 6, 128, 4, 1.7e-7
+MP_BLOCKS = (MP_N + MP_BLOCK - 1) // MP_BLOCK + 3  # the last block is ragged and three lie beyond the data
+
+
+def _mp_thetas():
+    rng = np.random.default_rng(8)
+    return [rng.normal(0, 0.4, MP_D) for _ in range(5)]
+
+
+def _mp_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from mcmc_amd.distributed import ShardedLikelihood
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sl = ShardedLikelihood(MP_N, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
+    sl.local.fill_synthetic(SEED)
+    sl.mp_reset(MP_BLOCK, MP_BLOCKS)
+    out = [sl.mp_loglik(th, MP_BLOCK, MP_BLOCKS, MP_RF, call % MP_RF, 1234, call, MP_EPS)
+           for call, th in enumerate(_mp_thetas())]
+    q.put((rank, out))
+    dist.barrier()
+    sl.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_mixed_precision_equals_single_context_bitwise(world):
+    """mhlik_mp_loglik over row shards (the reference's mixed-precision path is single-GPU, mcmc_mp.cu:286): with
+    block-aligned segments every rank evaluates the data blocks of its own rows, and values, bright and dark counts of
+    a whole call sequence -- the indicators evolve from call to call -- are those of the single-context run, bit for
+    bit; the single-context run is tied to the oracle."""
+    import ctypes as C
+
+    import oracle_py as O
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for g in got[1:]:
+        assert g[1] == got[0][1]
+    X = synthetic_host(SEED, MP_N, MP_D)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    L = O.lib()
+    L.oracle_mp_likelihood.restype = C.c_double
+    L.oracle_mp_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    z = np.ones(MP_BLOCKS, dtype=np.int8)
+    with Likelihood(MP_N, MP_D, precision=3, device=0, segment_align=1024) as lk:  # 8 segments, one GPU
+        lk.fill_synthetic(SEED)
+        lk.mp_reset(MP_BLOCK, MP_BLOCKS)
+        for call, th in enumerate(_mp_thetas()):
+            one = lk.mp_loglik(th, MP_BLOCK, MP_BLOCKS, MP_RF, call % MP_RF, 1234, call, MP_EPS)
+            assert one == got[0][1][call], (call, one, got[0][1][call])
+            nb, nd = C.c_int(), C.c_int()
+            want = L.oracle_mp_likelihood(O.ptr(X), O.ptr(Xf), MP_N, MP_D, MP_N, O.ptr(th), MP_BLOCK, MP_BLOCKS, MP_RF,
+                                          call % MP_RF, 1234, call, MP_EPS, O.ptr(z), C.byref(nb), C.byref(nd))
+            assert (one[1], one[2]) == (nb.value, nd.value), (call, one, nb.value, nd.value)
+            assert abs(one[0] - want) <= 2e-6 * abs(want)
+        s_all, e_all = lk.mp_bound(_mp_thetas()[0])
+    eps = C.c_double()
+    L.oracle_mp_bound.restype = C.c_double
+    L.oracle_mp_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.POINTER(C.c_double)]
+    want_s = L.oracle_mp_bound(O.ptr(X), O.ptr(Xf), MP_N, MP_D, MP_N, O.ptr(_mp_thetas()[0]), C.byref(eps))
+    assert abs(s_all - want_s) <= 1e-10 * abs(want_s) and abs(e_all - eps.value) <= 1e-9
+
+
+def test_mixed_precision_needs_aligned_segments_and_rccl_path_with_one_rank(monkeypatch):
+    from mcmc_amd import Likelihood
+    from mcmc_amd._lib import MhlikError
+
+    th = _mp_thetas()[0]
+    with Likelihood(MP_N, MP_D, precision=3, device=0) as lk:  # 8 segments of 37501 rows: blocks would straddle them
+        lk.fill_synthetic(SEED)
+        lk.mp_reset(MP_BLOCK, MP_BLOCKS)
+        with pytest.raises(MhlikError, match="segment_align"):
+            lk.mp_loglik(th, MP_BLOCK, MP_BLOCKS, MP_RF, 0, 1234, 0, MP_EPS)
+    with Likelihood(MP_N, MP_D, precision=3, device=0, segment_align=1024) as lk:
+        lk.fill_synthetic(SEED)
+        lk.mp_reset(MP_BLOCK, MP_BLOCKS)
+        plain = [lk.mp_loglik(t, MP_BLOCK, MP_BLOCKS, MP_RF, i % MP_RF, 1234, i, MP_EPS) for i, t in enumerate(_mp_thetas())]
+        plain_bound = lk.mp_bound(th)
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")  # the in-stream all-reduce of the 3*segments slots, one rank
+    with Likelihood(MP_N, MP_D, precision=3, device=0, segment_align=1024) as lk:
+        lk.fill_synthetic(SEED)
+        lk.comm_init(Likelihood.make_comm_id())
+        lk.mp_reset(MP_BLOCK, MP_BLOCKS)
+        assert [lk.mp_loglik(t, MP_BLOCK, MP_BLOCKS, MP_RF, i % MP_RF, 1234, i, MP_EPS)
+                for i, t in enumerate(_mp_thetas())] == plain
+        assert lk.mp_bound(th) == plain_bound
