@@ -174,6 +174,17 @@ int mhlik_loglik_batched_end(mhlik_ctx *ctx, double *out);
 #define MHLIK_BATCHED_F32_SPLIT 1
 int mhlik_set_batched_f32_mode(mhlik_ctx *ctx, int32_t mode);
 
+/* How mhlik_loglik_batched_f64 turns the row dots into -log(1 + e^x) (no counterpart in the reference):
+ *   MHLIK_BATCHED_F64_FAST   (default) product form: a lane adds max(x, 0), multiplies the factors 1 + e^-|x| of its 32
+ *                            rows and takes one log of the product (mhlik_softplus.h) -- half the FP64 instructions,
+ *                            ~1e-16 relative on the lane's sum, rounding errors only (no bias);
+ *   MHLIK_BATCHED_F64_EXACT  -log(1 + e^x) per element, 6e-16 each, by full-length series.
+ * Both meet the 1e-10 contract of the summed log-likelihood with five orders of magnitude to spare; the row dots are
+ * the same.  The default can also be chosen with the environment variable MHLIK_BATCHED_F64=exact|fast. */
+#define MHLIK_BATCHED_F64_EXACT 0
+#define MHLIK_BATCHED_F64_FAST 1
+int mhlik_set_batched_f64_mode(mhlik_ctx *ctx, int32_t mode);
+
 /* Per-row dot products x_i.theta of this shard's rows, to a host array of
  * local-row-count doubles: the reference's data.mvout / d.cuLhood
  * (mcmc_cpu.c:436, mcmc_gpu.cu:233).  Test / debug entry point. */

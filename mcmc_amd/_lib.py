@@ -132,6 +132,7 @@ _SIGS = [
     ("mhlik_loglik_batched_begin_f32", C.c_int, [_P, _P, C.c_int32]),
     ("mhlik_loglik_batched_end", C.c_int, [_P, _P]),
     ("mhlik_set_batched_f32_mode", C.c_int, [_P, C.c_int32]),
+    ("mhlik_set_batched_f64_mode", C.c_int, [_P, C.c_int32]),
     ("mhlik_rowdots_f64", C.c_int, [_P, _P, _P]),
     ("mhlik_mp_reset", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("mhlik_mp_loglik", C.c_int, [_P, C.POINTER(MpState), _P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -198,6 +198,7 @@ struct mhlik_ctx {
   double *rowdots = nullptr;
   size_t rowdots_cap = 0;
   int batched_f32_mode = MHLIK_BATCHED_F32_SPLIT; // mhlik_set_batched_f32_mode
+  int batched_f64_mode = MHLIK_BATCHED_F64_FAST;  // mhlik_set_batched_f64_mode
   // an evaluation begun with mhlik_*_begin and not yet collected with the matching _end
   int pending_kind = 0; // 0 none, 1 batched, 2 mixed-precision batched
   int pending_nvec = 0;
@@ -757,6 +758,8 @@ int mhlik_create(const mhlik_config *cfg, mhlik_ctx **out)
   c->compute_units = prop.multiProcessorCount;
   if (const char *e = getenv("MHLIK_BATCHED_F32")) // "exact" | "split": default of mhlik_set_batched_f32_mode
     c->batched_f32_mode = strcmp(e, "exact") == 0 ? MHLIK_BATCHED_F32_EXACT : MHLIK_BATCHED_F32_SPLIT;
+  if (const char *e = getenv("MHLIK_BATCHED_F64")) // "exact" | "fast": default of mhlik_set_batched_f64_mode
+    c->batched_f64_mode = strcmp(e, "exact") == 0 ? MHLIK_BATCHED_F64_EXACT : MHLIK_BATCHED_F64_FAST;
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&c->ev0));
   CREATE_CHK(hipEventCreate(&c->ev1));

@@ -201,18 +201,21 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 // f64 tile = 512 rows; wave w owns rows [128w, 128w+128) in two passes of 64
 // rows (16 A-rows x 4 row sets: two double2 loads per lane per k-step).
 // NB = number of 16-chain blocks (1..4).  One k-step = 4 columns.
-// LDS: thetaL[(j*16 + c)*4 + n] = Theta[j][n*16 + c]  (4 doubles per (j, c)).
+// LDS: thetaL[(j*16 + c)*4 + n] = Theta[j][n*16 + c]  (4 doubles per (j, c)); the per-chain reduction buffer
+// [4 waves][NB][64 lanes] reuses that region once the last MFMA has read Theta (theta_doubles >= 4*NB*64).
+// EXP & 8: the product-form epilogue of mhlik_softplus.h (one log per lane and chain block instead of one per element).
 template <int NB, int KU, int EXP = 0>
 __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double *__restrict__ X, TileGeom g,
                                                                     const int32_t *__restrict__ tile_valid,
                                                                     const double *__restrict__ theta_dev, int d_pad,
                                                                     double *__restrict__ partials, int64_t pstride,
-                                                                    int K)
+                                                                    int K, int theta_doubles)
 {
   typedef Vec16<double>::type V2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *thetaL = reinterpret_cast<double *>(smem);                  // d_pad * 64 doubles
-  double *red = thetaL + (size_t)d_pad * kBatchCols;                  // [4 waves][NB][64 lanes]
+  double *thetaL = reinterpret_cast<double *>(smem);                  // d_pad * 64 doubles (region: theta_doubles)
+  double *red = thetaL;                                               // [4 waves][NB][64 lanes], after the last pass
+  (void)theta_doubles;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
@@ -227,8 +230,12 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
   const int kk = lane >> 4;   // which of the four columns of a k-step
   const double *tbase = X + tile * g.tile_stride;
   double sum[NB];
+  mhlik_softplus_acc pacc[NB]; // EXP & 8: 32 elements per lane and chain block over the two passes
 #pragma unroll
-  for (int n = 0; n < NB; n++) sum[n] = 0.0;
+  for (int n = 0; n < NB; n++) {
+    sum[n] = 0.0;
+    mhlik_softplus_acc_init(&pacc[n]);
+  }
 
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
@@ -312,10 +319,20 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         const bool ok = full || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
 #pragma unroll
         for (int n = 0; n < NB; n++)
-          if (ok) sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
+          if (ok) {
+            if constexpr ((EXP & 8) != 0)
+              mhlik_softplus_acc_add(&pacc[n], acc[m][n][r]);
+            else
+              sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
+          }
       }
   }
+  if constexpr ((EXP & 8) != 0) {
+#pragma unroll
+    for (int n = 0; n < NB; n++) sum[n] = mhlik_softplus_acc_neg_sum(&pacc[n]);
+  }
 
+  __syncthreads(); // every wave is done with Theta: the reduction buffer takes its place
 #pragma unroll
   for (int n = 0; n < NB; n++) red[(wave * NB + n) * 64 + lane] = sum[n];
   __syncthreads();

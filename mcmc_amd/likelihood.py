@@ -149,6 +149,10 @@ class Likelihood:
         """'exact' (f32 MFMA, the single-theta kernel's fmaf chain) or 'split' (three bfloat16 pieces, default)."""
         self.set_batched_f32_mode_raw({"exact": 0, "split": 1}[mode])
 
+    def set_batched_f64_mode(self, mode):
+        """'fast' (table-driven softplus, default) or 'exact' (full-length series) epilogue of the double K-chain pass."""
+        self._chk(self._lib.mhlik_set_batched_f64_mode(self._ctx, {"exact": 0, "fast": 1}[mode]))
+
     def set_batched_f32_mode_raw(self, mode):
         self._chk(self._lib.mhlik_set_batched_f32_mode(self._ctx, int(mode)))
 

@@ -14,7 +14,10 @@ def _oracle_batched(X, Theta):
 
 @pytest.mark.parametrize("N,d,K", [(4096, 8, 64), (10000, 3, 5), (5000, 16, 33), (3000, 128, 64), (1025, 7, 1),
                                    (20000, 64, 16), (513, 1, 64), (70001, 10, 48)])
-def test_batched_f64_matches_oracle(N, d, K):
+@pytest.mark.parametrize("f64_mode", ["fast", "exact"])
+def test_batched_f64_matches_oracle(N, d, K, f64_mode):
+    """Both epilogues of the double pass (table-driven softplus, the default, and the full-length series) against K
+    oracle evaluations, to the DP bar of 1e-10 on the sum; the two agree with each other to 1e-13."""
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
 
@@ -23,10 +26,43 @@ def test_batched_f64_matches_oracle(N, d, K):
     want = _oracle_batched(X, Theta)
     with Likelihood(N, d) as lk:
         lk.upload(X)
+        lk.set_batched_f64_mode(f64_mode)
         got = lk.loglik_batched(Theta)
         single = np.array([lk.loglik(th) for th in Theta[:4]])
+        lk.set_batched_f64_mode("exact" if f64_mode == "fast" else "fast")
+        other = lk.loglik_batched(Theta)
     assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs(got - want).max()
     assert np.all(np.abs(got[:4] - single) <= 1e-10 * np.abs(single))
+    assert np.all(np.abs(got - other) <= 1e-13 * np.abs(want)), (np.abs(got - other) / np.abs(want)).max()
+
+
+def test_batched_f64_fast_mode_extremes_and_full_size_sum():
+    """The table-driven epilogue where its table ends: dots far beyond +-37.65 (exactly 0 / x like the reference's
+    formula), overflow above 709.78 (-inf), and a sum over 2e6 rows x 64 chains against the exact mode (no drift)."""
+    from mcmc_amd import Likelihood
+
+    N, d = 4000, 2
+    X = np.zeros((N, d), order="F")
+    X[:, 0] = 1.0
+    X[:, 1] = np.linspace(-1, 1, N)
+    Theta = np.array([[50.0, 30.0], [-50.0, 30.0], [800.0, 0.0], [-800.0, 0.0], [0.0, 0.0], [37.6, 0.1], [-37.7, 0.05]])
+    want = _oracle_batched(X, Theta)
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        got = lk.loglik_batched(Theta)
+    for g, w in zip(got, want):
+        if np.isinf(w):
+            assert g == w
+        else:
+            assert abs(g - w) <= 1e-10 * abs(w) + 1e-12, (g, w)  # sums of terms below 1e-16 each: absolute
+    N, d, K = 2_000_000, 16, 64
+    Theta = np.random.default_rng(1).normal(0, 0.5, (K, d))
+    with Likelihood(N, d) as lk:
+        lk.fill_synthetic(3)
+        fast = lk.loglik_batched(Theta)
+        lk.set_batched_f64_mode("exact")
+        exact = lk.loglik_batched(Theta)
+    assert np.max(np.abs(fast - exact) / np.abs(exact)) <= 1e-14
 
 
 @pytest.mark.parametrize("mode", ["exact", "split"])

@@ -118,7 +118,7 @@ int main(int argc, char **argv)
 #define RUN64(EXPV, label) RUN64K(2, EXPV, label)
 #define RUN64K(KUV, EXPV, label) { auto k = lik_batched_f64_kernel<4, KUV, EXPV>; \
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
+      float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K, d * 64); }, reps); \
       printf("f64 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
     std::vector<double> href((size_t)ntiles * 64);
 #define RUNILV(NKV, EXPV, label) if (d == 4 * NKV) { auto k = lik_batched_f64_ilv_kernel<NKV, EXPV>; \
@@ -139,6 +139,7 @@ int main(int argc, char **argv)
     RUN64(2, "no global loads in k-loop")
     RUN64(3, "neither")
     RUN64K(4, 0, "KU=4")
+    RUN64(8, "product-form epilogue")
   }
   return 0;
 }
