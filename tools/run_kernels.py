@@ -31,7 +31,12 @@ with Likelihood(N, 128, precision=3, segments=1) as lk:  # batched at d=128, K=6
         lk.loglik_batched(Th.astype(np.float32), dtype=np.float32)
         lk.set_batched_f32_mode("split")  # three bf16 pieces
         lk.loglik_batched(Th.astype(np.float32), dtype=np.float32)
+        lk.set_batched_f64_mode("fast")  # product-form epilogue (default)
         lk.loglik_batched(Th, dtype=np.float64)
+    lk.set_batched_f64_mode("exact")  # per-element series: the other instantiation of lik_batched_f64_kernel
+    for _ in range(2):
+        lk.loglik_batched(Th, dtype=np.float64)
+    lk.set_batched_f64_mode("fast")
     blocks = N // 64
     seeds = np.full(64, 1234, dtype=np.uint64)
     for mode in ("exact", "split"):
@@ -39,4 +44,8 @@ with Likelihood(N, 128, precision=3, segments=1) as lk:  # batched at d=128, K=6
         lk.mp_reset_batched(64, blocks, 64)
         for call in range(reps + 1):
             lk.mp_loglik_batched(Th, 16, np.full(64, call % 16), seeds, call, 1.7e-7)
+    # one phase per chain (K independent mp_sampler runs): the per-(block, chain) correction kernel, mpb_fix_kernel
+    lk.mp_reset_batched(64, blocks, 64)
+    for call in range(reps + 1):
+        lk.mp_loglik_batched(Th, 16, (np.arange(64) + call) % 16, seeds, call, 1.7e-7)
 print("done")
