@@ -28,6 +28,8 @@
 // tile): partials[chain*pstride + tile], reduced by segment_sum_kernel.
 #pragma once
 
+#include <type_traits>
+
 #include "mhlik_kernels.hpp"
 #include "mhlik_softplus.h"
 
@@ -46,6 +48,38 @@ __device__ __forceinline__ float neg_log1pexp_fast(float x)
   const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
   return -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);
 }
+
+// Product form of the float epilogue (the float twin of mhlik_softplus.h's): a lane needs the SUM of
+// log(1 + e^x) over its rows, and  sum_i log(1 + e^x_i) = sum_i max(x_i, 0) + log prod_i (1 + e^-|x_i|).
+// Every factor lies in (1, 2], so up to 64 of them are multiplied without rescaling (the callers take the log
+// after at most 64) and the lane takes ONE log per group: per element one v_exp_f32 and four full-rate
+// instructions instead of v_exp_f32 + v_log_f32 and five.  prod + prod*y is a single rounding of prod*(1 + y);
+// over 64 factors the product is within ~5e-7 relative, i.e. the log within 5e-7 ABSOLUTE on a value of order
+// 40 -- less than the float additions of 64 separate terms lose.
+struct SoftplusAccF {
+  float lin = 0.f;   // sum of max(x, 0)
+  float prod = 1.f;  // product of (1 + e^-|x|)
+  __device__ __forceinline__ void add(float x)
+  {
+    float pos; // one v_max_f32 (fmaxf() canonicalises x first); NaN -> 0 here, and NaN again through the product
+    __asm__("v_max_f32 %0, %1, 0" : "=v"(pos) : "v"(x));
+    lin += pos;
+    prod = fmaf(prod, __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f), prod);
+  }
+  // -inf above the point where the reference's float formula overflows (expf(x) = inf for x > 88.72): the adds do
+  // not test for it; a group whose linear part got that far is looked over again, element by element
+  static constexpr float kOverflow = 88.7228394f;
+  __device__ __forceinline__ void flag_overflow(float x)
+  {
+    if (x > kOverflow) lin = __builtin_inff();
+  }
+  __device__ __forceinline__ float neg_sum() const { return -(lin + 0.69314718055994531f * __builtin_amdgcn_logf(prod)); }
+  __device__ __forceinline__ void reset()
+  {
+    lin = 0.f;
+    prod = 1.f;
+  }
+};
 
 // One 128-row pass of a wave: acc[m][n] = rows {row0 + 4i + m} x chains of
 // N-block n, accumulated over all d columns.  ubase = tile + row0 (wave-uniform): a load's address is a
@@ -163,24 +197,39 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 
     // epilogue: accumulator (m, n, r) of lane l is tile row  row0 + 4*i + m  with
     // i = (r&3) + 8*(r>>2) + 4*(l>>5), chain n*32 + (l&31)
-    if (row0 + 128 <= valid) {
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < NB; n++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) sum[n] += (EXP & 1) ? acc[m][n][r] : neg_log1pexp_fast(acc[m][n][r]);
-    } else {
+    // Product form (SoftplusAccF): a lane's 64 elements per chain block and pass share one log.
+    SoftplusAccF sp[NB];
+    auto each = [&](auto full_tag, auto fn) { // only a shard's last tile is ragged: the full case has no predicates
+      constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * kk;
-          const bool ok = row0 + 4 * i + m < valid;
+          const bool ok = kFull || (row0 + 4 * i + m < valid);
 #pragma unroll
-          for (int n = 0; n < NB; n++) sum[n] += ok ? neg_log1pexp_fast(acc[m][n][r]) : 0.f;
+          for (int n = 0; n < NB; n++)
+            if (ok) fn(n, acc[m][n][r]);
         }
+    };
+    auto add = [&](int n, float x) {
+      if (EXP & 1)
+        sp[n].lin -= x;
+      else
+        sp[n].add(x);
+    };
+    if (row0 + 128 <= valid)
+      each(std::true_type{}, add);
+    else
+      each(std::false_type{}, add);
+    if (!(EXP & 1)) {
+      bool look = false;
+#pragma unroll
+      for (int n = 0; n < NB; n++) look |= sp[n].lin > SoftplusAccF::kOverflow;
+      if (look) each(std::false_type{}, [&](int n, float x) { sp[n].flag_overflow(x); });
     }
+#pragma unroll
+    for (int n = 0; n < NB; n++) sum[n] += (EXP & 1) ? -sp[n].lin : sp[n].neg_sum();
   }
 
   // per-chain sum over the workgroup: [wave][n][lane] -> thread per chain, fixed order
@@ -214,7 +263,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
   typedef Vec16<double>::type V2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *thetaL = reinterpret_cast<double *>(smem);                  // d_pad * 64 doubles (region: theta_doubles)
-  double *red = thetaL;                                               // [4 waves][NB][64 lanes], after the last pass
+  double *red = thetaL;                                               // [4 waves][NB][64 lanes] (product form: twice), after the last pass
   (void)theta_doubles;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -309,30 +358,72 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
     }
 
     // accumulator (m, n, r) of lane l: A-row i = (l>>4) + 4*r, chain n*16 + (l&15);
-    // tile row = row0 + (m>>1)*32 + 2*i + (m&1)
+    // tile row = row0 + (m>>1)*32 + 2*i + (m&1).  Only the last tile of a shard is ragged: the full case is
+    // straight-line code with no per-element predicate.
     const bool full = row0 + 64 <= valid;
+    auto epilogue = [&](auto full_tag) {
+      constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+      for (int m = 0; m < 4; m++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int i = kk + 4 * r;
-        const bool ok = full || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
+        for (int r = 0; r < 4; r++) {
+          const int i = kk + 4 * r;
+          const bool ok = kFull || (row0 + (m >> 1) * 32 + 2 * i + (m & 1) < valid);
 #pragma unroll
-        for (int n = 0; n < NB; n++)
-          if (ok) {
-            if constexpr ((EXP & 8) != 0)
-              mhlik_softplus_acc_add(&pacc[n], acc[m][n][r]);
-            else
-              sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
-          }
-      }
+          for (int n = 0; n < NB; n++)
+            if (ok) {
+              if constexpr ((EXP & 8) != 0)
+                mhlik_softplus_acc_add(&pacc[n], acc[m][n][r]);
+              else
+                sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
+            }
+        }
+    };
+    if (full)
+      epilogue(std::true_type{});
+    else
+      epilogue(std::false_type{});
+    if constexpr ((EXP & 8) != 0) {
+      // the adds do not test for the reference's overflow to -inf above 709.78: a group whose linear part got
+      // there is looked over while its elements are still in the accumulators
+#pragma unroll
+      for (int n = 0; n < NB; n++)
+        if (pacc[n].lin > MHLIK_SOFTPLUS_OVERFLOW) {
+#pragma unroll
+          for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (full || (row0 + (m >> 1) * 32 + 2 * (kk + 4 * r) + (m & 1) < valid))
+                mhlik_softplus_acc_flag_overflow(&pacc[n], acc[m][n][r]);
+        }
+    }
   }
-  if constexpr ((EXP & 8) != 0) {
-#pragma unroll
-    for (int n = 0; n < NB; n++) sum[n] = mhlik_softplus_acc_neg_sum(&pacc[n]);
-  }
-
   __syncthreads(); // every wave is done with Theta: the reduction buffer takes its place
+  if constexpr ((EXP & 8) != 0) {
+    // product form: a chain's 16 lane groups are merged first, one log per (tile, chain)
+    double *red_prod = red + 4 * NB * 64;
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+      red[(wave * NB + n) * 64 + lane] = pacc[n].lin;
+      red_prod[(wave * NB + n) * 64 + lane] = pacc[n].prod;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NB * 16) {
+      const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
+      mhlik_softplus_acc t;
+      mhlik_softplus_acc_init(&t);
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const mhlik_softplus_acc e{red[(w * NB + n) * 64 + c + 16 * q], red_prod[(w * NB + n) * 64 + c + 16 * q]};
+          mhlik_softplus_acc_merge(&t, &e);
+        }
+      const int chain = n * 16 + c;
+      if (chain < K) partials[(int64_t)chain * pstride + tile] = mhlik_softplus_acc_neg_sum(&t);
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < NB; n++) red[(wave * NB + n) * 64 + lane] = sum[n];
   __syncthreads();

@@ -67,6 +67,46 @@ __device__ __forceinline__ void x3_split(const V4 (&x)[8], int m, bf16x8 &fa, bf
   fc = __builtin_bit_cast(bf16x8, uc);
 }
 
+// Lab variant (EXP & 512): the same for all four row sets of a block at once, written on whole loaded vectors
+// (4 adjacent rows of one column): the two exact subtractions of a vector are two v_pk_add_f32 each instead of
+// four v_sub_f32, which takes a sixth off the split's instructions.  Same pieces, same bits as x3_split -- and
+// 4 % slower in the full kernel (tools/x3_ablate, profiles/r02_x3_ablate.txt), so the kernel splits row set by
+// row set.
+template <typename V4>
+__device__ __forceinline__ void x3_split_all(const V4 (&x)[8], bf16x8 (&fa)[4], bf16x8 (&fb)[4], bf16x8 (&fc)[4])
+{
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto residual2 = [](f32x2 v) -> f32x2 {
+    const u32x2 top = __builtin_bit_cast(u32x2, v) & 0xffff0000u;
+    return v - __builtin_bit_cast(f32x2, top);
+  };
+  u32x4 ua[4], ub[4], uc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const V4 v0 = x[2 * i], v1 = x[2 * i + 1];
+#pragma unroll
+    for (int h = 0; h < 2; h++) { // rows 2h, 2h+1 of both columns
+      const f32x2 p0 = {v0[2 * h], v0[2 * h + 1]}, p1 = {v1[2 * h], v1[2 * h + 1]};
+      const f32x2 s0 = residual2(p0), s1 = residual2(p1);
+      const f32x2 t0 = residual2(s0), t1 = residual2(s1);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int m = 2 * h + e;
+        ua[m][i] = x3_pack_hi(p0[e], p1[e]);
+        ub[m][i] = x3_pack_hi(s0[e], s1[e]);
+        uc[m][i] = x3_pack_hi(t0[e], t1[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    fa[m] = __builtin_bit_cast(bf16x8, ua[m]);
+    fb[m] = __builtin_bit_cast(bf16x8, ub[m]);
+    fc[m] = __builtin_bit_cast(bf16x8, uc[m]);
+  }
+}
+
 // A wave's share of one 1024-row tile: four passes of 64 rows (pass p of wave w: tile rows 256p + 64w ..,
 // so the four waves of a workgroup read 1 KB of every column side by side), each over d_pad/32 k-blocks.
 // v_mfma_f32_16x16x32_bf16: A[row l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col l&15], C: col = l&15,
@@ -124,8 +164,12 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
   };
   bf16x8 fa[4], fb[4], fc[4];
   auto split_block = [&](const V4 (&buf)[8]) {
+    if (EXP & 512) { // lab: whole vectors at once, packed subtractions -- fewer instructions, 4 % slower (tools/x3_ablate)
+      x3_split_all(buf, fa, fb, fc);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 4; m++) x3_split(buf, m, fa[m], fb[m], fc[m]);
+      for (int m = 0; m < 4; m++) x3_split(buf, m, fa[m], fb[m], fc[m]);
+    }
   };
   auto mfma_block = [&](int kb) { // chain block outermost: three Theta fragments live at a time
     const u32x4 *tb = thetaL + (size_t)kb * NB * 3 * 64 + lane;
@@ -232,11 +276,19 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
       finish_ilv(buf, more);
       return;
     }
+    if (EXP & 256) __builtin_amdgcn_s_barrier(); // lab: the four waves of a workgroup stay on the same (pass, k-block)
     if (EXP & 4) { // lab: loads only
 #pragma unroll
       for (int u = 0; u < 8; u++)
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m][0][u & 3] += buf[u][m];
+    } else if (EXP & 64) { // lab: no split -- the fragments are the loaded registers as they are (the loads stay live)
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        fa[m] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(buf[0][m]), __float_as_uint(buf[1][m]), __float_as_uint(buf[2][m]), __float_as_uint(buf[3][m])});
+        fb[m] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(buf[4][m]), __float_as_uint(buf[5][m]), __float_as_uint(buf[6][m]), __float_as_uint(buf[7][m])});
+        fc[m] = fa[m];
+      }
     } else {
       split_block(buf);
     }
@@ -246,7 +298,14 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
       advance(l);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(EXP & 4)) mfma_block(w.kb);
+    if (EXP & 32) { // lab: no MFMAs -- the split's results are kept live, the accumulators take one word of each
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        __asm__ volatile("" ::"v"(fa[m]), "v"(fb[m]), "v"(fc[m]));
+        acc[m][0][0] += __uint_as_float(__builtin_bit_cast(u32x4, fc[m])[0]);
+      }
+    } else if (!(EXP & 4))
+      mfma_block(w.kb);
     __builtin_amdgcn_sched_barrier(0);
     if (w.kb == nkb - 1) {
       epi(w.tile, w.pass * 256 + wave * 64, acc);
@@ -315,29 +374,49 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_x3_kernel(const float *
   __syncthreads();
 
   const int grp = lane >> 4;
-  float sum[NB];
-#pragma unroll
-  for (int n = 0; n < NB; n++) sum[n] = 0.f;
+  SoftplusAccF sp[NB]; // product-form epilogue: a lane's 64 elements per chain block and tile (16 per pass)
   // accumulator (m, n, r) of lane l: tile row row0 + 4*(4*(l>>4) + r) + m, chain 16n + (l&15)
   auto epi = [&](int64_t tile, int row0, const f32x4 (&acc)[4][NB]) {
     const int valid = tile_valid[tile];
+    auto each = [&](auto full_tag, auto fn) { // only a shard's last tile is ragged: the full case has no predicates
+      constexpr bool kFull = decltype(full_tag)::value;
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool ok = kFull || (row0 + 4 * (4 * grp + r) + m < valid);
+#pragma unroll
+          for (int n = 0; n < NB; n++)
+            if (ok) fn(n, acc[m][n][r]);
+        }
+    };
+    auto add = [&](int n, float x) {
+      if (EXP & 1)
+        sp[n].lin += x;
+      else if (EXP & 128) // lab: one v_exp_f32 and one v_log_f32 per element
+        sp[n].lin -= neg_log1pexp_fast(x);
+      else
+        sp[n].add(x);
+    };
+    auto flag = [&](int n, float x) { sp[n].flag_overflow(x); };
     const bool full = row0 + 64 <= valid;
+    if (full)
+      each(std::true_type{}, add);
+    else
+      each(std::false_type{}, add);
+    if (!(EXP & 1)) {
+      bool look = false;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const bool ok = full || (row0 + 4 * (4 * grp + r) + m < valid);
-#pragma unroll
-        for (int n = 0; n < NB; n++)
-          sum[n] += ok ? ((EXP & 1) ? acc[m][n][r] : neg_log1pexp_fast(acc[m][n][r])) : 0.f;
-      }
+      for (int n = 0; n < NB; n++) look |= sp[n].lin > SoftplusAccF::kOverflow; // the tile's sum so far: a superset
+      if (look) each(std::false_type{}, flag);
+    }
   };
   // per-chain sum over the tile: [wave][n][lane] -> thread per chain, fixed order
   auto tile_done = [&](int64_t tile) {
 #pragma unroll
     for (int n = 0; n < NB; n++) {
-      red[(wave * NB + n) * 64 + lane] = (double)sum[n];
-      sum[n] = 0.f;
+      red[(wave * NB + n) * 64 + lane] = (double)((EXP & 1) ? sp[n].lin : sp[n].neg_sum());
+      sp[n].reset();
     }
     __syncthreads();
     if ((int)threadIdx.x < NB * 16) {

@@ -97,31 +97,84 @@ MHLIK_SP double mhlik_neg_softplus(double x)
  * (mhlik_set_batched_f64_mode(FAST)).
  *
  * What the kernel needs is not s(x_i) for every element but the SUM over the
- * rows a lane holds, and  sum_i log(1 + y_i) = log prod_i (1 + y_i):
+ * rows of a tile, and  sum_i log(1 + y_i) = log prod_i (1 + y_i):
  *
  *   sum_i s(x_i) = sum_i max(x_i, 0) + log( prod_i (1 + e^-|x_i|) )
  *
- * Every factor lies in (1, 2], a lane multiplies 32 of them per (tile, chain
- * block) -- the product stays below 2^32, no rescaling -- and takes ONE log at
- * the end.  Per element that leaves e^-|x| (18 FP64 instructions), one add, one
- * multiply and the max/add of the linear part: 22 instructions instead of 45,
- * with no table and no data-dependent cost (a table-driven log1p was tried: its
- * LDS reads cost more than they save once the dots of a wave spread over many
- * table entries).  Error: each factor and each multiplication is rounded to
- * nearest (relative 1.1e-16, unbiased), so a product of 32 factors is within
- * ~1e-15 relative and its log within ~1e-15 ABSOLUTE on a value of order 20;
- * the exp is < 3e-16.  The rounding of each factor 1 + y is the rounding the
- * reference's own log(1 + exp(x)) makes: 1.1e-16 ABSOLUTE per element (a term
- * with e^-|x| < 2^-53 is dropped, there as here), so a lane's sum is within
- * 2e-15 |sum| + 4e-15 of the exact one (tools/check_softplus.hip) -- relative
- * accuracy for sums of order one, absolute for sums of tiny terms, where the
- * EXACT mode (which keeps tiny terms to relative accuracy) is the better of
- * the two and also differs from the reference's formula.
- * mhlik_softplus_group_sum is the host statement of what a lane does (used by
- * tests/test_softplus.py to measure accuracy and bias against 80-bit sums).
+ * Every factor lies in (1, 2]: a lane multiplies the 32 of its rows, the 16
+ * lane products of a chain are multiplied when the tile is finished (512
+ * factors: below 2^512, no rescaling) and ONE log is taken per (tile, chain).
+ * Per element that leaves e^-|x| (16 FP64 instructions: mhlik_exp_neg_fast),
+ * one fma for  prod += prod * y  and the max/add of the linear part: 19
+ * instructions instead of the 45 of mhlik_neg_softplus, with no table and no
+ * data-dependent cost (a table-driven log1p was tried: its LDS reads cost more
+ * than they save once the dots of a wave spread over many table entries).
+ * Error: prod + prod*y is ONE rounding to nearest of prod*(1 + y) (relative
+ * 1.1e-16, unbiased), so a product of 32 factors is within ~1e-15 relative
+ * and its log within ~1e-15 ABSOLUTE on a value of order 20; the exp is
+ * < 5e-16.  That rounding is no worse than the one the reference's own
+ * log(1 + exp(x)) makes when it forms 1 + exp(x): 1.1e-16 ABSOLUTE per
+ * element (a term with e^-|x| < 2^-53 is dropped, there as here), so a lane's
+ * sum is within 2e-15 |sum| + 4e-15 of the exact one (tools/check_softplus.hip)
+ * -- relative accuracy for sums of order one, absolute for sums of tiny terms,
+ * where the EXACT mode (which keeps tiny terms to relative accuracy) is the
+ * better of the two and also differs from the reference's formula.
+ * Overflow: the reference's formula gives -inf above x = 709.78.  The adds do
+ * not test for it; a group whose linear part exceeds that value is looked
+ * over again with mhlik_softplus_acc_flag_overflow (the kernel does so while
+ * the elements are still in registers).
+ * tests/test_softplus.py states a lane's work on the host and measures
+ * accuracy and bias against 80-bit sums.
  * -------------------------------------------------------------------------*/
+#define MHLIK_SOFTPLUS_OVERFLOW 709.782712893383973096
+
+/* e^-u for u >= 0, the product form's factor: as mhlik_exp_neg with a degree-10 minimax polynomial (c0 = c1 = 1;
+ * relative error 2.9e-16 equi-rippled over |r| <= ln2/2, from a Remez exchange in 60-digit arithmetic) instead
+ * of the degree-12 Taylor one; < 5e-16 relative with the roundings; u > 745 underflows to 0; NaN stays NaN. */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* A coefficient as an opaque scalar-register value: v_fma_f64 takes it as its one scalar operand.  Left to
+ * itself the compiler keeps the coefficients in vector registers and forms every Horner step as a copy of the
+ * coefficient plus v_fmac_f64 -- a third more instructions for the same bits. */
+#define MHLIK_SP_COEF(name, value) \
+  double name = value;             \
+  __asm__("" : "+s"(name))
+#else
+#define MHLIK_SP_COEF(name, value) const double name = value
+#endif
+
+MHLIK_SP double mhlik_exp_neg_fast(double u)
+{
+  MHLIK_SP_COEF(log2e, 1.4426950408889634074);
+  MHLIK_SP_COEF(ln2hi, -6.93147180369123816490e-01);
+  MHLIK_SP_COEF(ln2lo, -1.90821492927058770002e-10);
+  MHLIK_SP_COEF(c10, 0x1.2707a75412ea7p-22);
+  MHLIK_SP_COEF(c9, 0x1.72e91b12ab2d6p-19);
+  MHLIK_SP_COEF(c8, 0x1.a01b7c4e4defdp-16);
+  MHLIK_SP_COEF(c7, 0x1.a0198d583e339p-13);
+  MHLIK_SP_COEF(c6, 0x1.6c16c0c8318e3p-10);
+  MHLIK_SP_COEF(c5, 0x1.11111125b3ec8p-7);
+  MHLIK_SP_COEF(c4, 0x1.55555555890c1p-5);
+  MHLIK_SP_COEF(c3, 0x1.55555555507c5p-3);
+  MHLIK_SP_COEF(c2, 0x1.ffffffffffed2p-2);
+  const double t = -u;
+  const double fn = rint(t * log2e);
+  double r = fma(fn, ln2hi, t);
+  r = fma(fn, ln2lo, r);
+  double p = fma(c10, r, c9);
+  p = fma(p, r, c8);
+  p = fma(p, r, c7);
+  p = fma(p, r, c6);
+  p = fma(p, r, c5);
+  p = fma(p, r, c4);
+  p = fma(p, r, c3);
+  p = fma(p, r, c2);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)fn);
+}
+
 typedef struct {
-  double lin;  /* sum of max(x, 0); +inf once an x above 709.78 was seen (the reference's formula overflows there) */
+  double lin;  /* sum of max(x, 0); +inf once an x above 709.78 was flagged (the reference's formula overflows there) */
   double prod; /* product of (1 + e^-|x|) */
 } mhlik_softplus_acc;
 
@@ -133,11 +186,30 @@ MHLIK_SP void mhlik_softplus_acc_init(mhlik_softplus_acc *a)
 
 MHLIK_SP void mhlik_softplus_acc_add(mhlik_softplus_acc *a, double x)
 {
-  a->lin += x > 709.782712893383973096 ? HUGE_VAL : (x > 0.0 ? x : 0.0);
-  a->prod *= 1.0 + mhlik_exp_neg(fabs(x));
+#if defined(__HIP_DEVICE_COMPILE__)
+  double pos; /* max(x, 0) in one instruction: fmax() adds a canonicalising v_max_f64 x, x in front; NaN -> 0 either way */
+  __asm__("v_max_f64 %0, %1, 0" : "=v"(pos) : "v"(x));
+  a->lin += pos;
+#else
+  a->lin += x > 0.0 ? x : 0.0;
+#endif
+  a->prod = fma(a->prod, mhlik_exp_neg_fast(fabs(x)), a->prod);
 }
 
-/* - sum of log(1 + e^x) over everything added (at most ~1000 elements: the product must stay finite) */
+/* second look at an element of a group whose lin exceeded MHLIK_SOFTPLUS_OVERFLOW */
+MHLIK_SP void mhlik_softplus_acc_flag_overflow(mhlik_softplus_acc *a, double x)
+{
+  if (x > MHLIK_SOFTPLUS_OVERFLOW) a->lin = HUGE_VAL;
+}
+
+/* a += b: the elements of both groups (at most ~1000 elements altogether: the product must stay finite) */
+MHLIK_SP void mhlik_softplus_acc_merge(mhlik_softplus_acc *a, const mhlik_softplus_acc *b)
+{
+  a->lin += b->lin;
+  a->prod *= b->prod;
+}
+
+/* - sum of log(1 + e^x) over everything added */
 MHLIK_SP double mhlik_softplus_acc_neg_sum(const mhlik_softplus_acc *a) { return -(a->lin + log(a->prod)); }
 
 #endif

@@ -57,6 +57,7 @@ int main(void){
   for (long g = 0; g < 200000; g++) {
     mhlik_softplus_acc a; mhlik_softplus_acc_init(&a);
     long double want = 0;
+    double xs[32];
     const int regime = (int)(g % 4);
     for (int i = 0; i < 32; i++) {
       st ^= st << 13; st ^= st >> 7; st ^= st << 17;
@@ -66,14 +67,28 @@ int main(void){
       if (regime == 2) x = -700.0 + 1400.0 * r;    /* far tails */
       if (regime == 3) x = -30.0 - 20.0 * r;       /* every factor within 1e-13 of 1: tiny terms */
       mhlik_softplus_acc_add(&a, x);
+      xs[i] = x;
       const long double xl = x;
       want -= fmaxl(xl, 0) + log1pl(expl(-fabsl(xl)));
     }
+    if (a.lin > MHLIK_SOFTPLUS_OVERFLOW)   /* what the kernel does at the end of a pass */
+      for (int i = 0; i < 32; i++) mhlik_softplus_acc_flag_overflow(&a, xs[i]);
     const double got = mhlik_softplus_acc_neg_sum(&a), w = (double)want, lo = (double)(want - (long double)w);
     fwrite(&got, 8, 1, stdout); fwrite(&w, 8, 1, stdout); fwrite(&lo, 8, 1, stdout);
   }
   mhlik_softplus_acc o; mhlik_softplus_acc_init(&o);
   mhlik_softplus_acc_add(&o, 1.0); mhlik_softplus_acc_add(&o, 710.0);
+  if (!(o.lin > MHLIK_SOFTPLUS_OVERFLOW)) return 2;
+  mhlik_softplus_acc_flag_overflow(&o, 1.0); mhlik_softplus_acc_flag_overflow(&o, 710.0);
+  /* 16 lane groups merged as the kernel merges them: 512 factors of 2 stay finite */
+  mhlik_softplus_acc t; mhlik_softplus_acc_init(&t);
+  for (int q = 0; q < 16; q++) {
+    mhlik_softplus_acc e; mhlik_softplus_acc_init(&e);
+    for (int i = 0; i < 32; i++) mhlik_softplus_acc_add(&e, 0.0);
+    mhlik_softplus_acc_merge(&t, &e);
+  }
+  const double tl = mhlik_softplus_acc_neg_sum(&t);
+  if (!(fabs(tl + 512.0 * 0.69314718055994530942) < 1e-12)) return 3;
   mhlik_softplus_acc n; mhlik_softplus_acc_init(&n);
   mhlik_softplus_acc_add(&n, 0.0 / 0.0);
   const double on = mhlik_softplus_acc_neg_sum(&o), nn = mhlik_softplus_acc_neg_sum(&n);

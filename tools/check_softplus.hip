@@ -19,6 +19,8 @@ __global__ void kgroup(const double *x, double *f, int ngroups)
   mhlik_softplus_acc a;
   mhlik_softplus_acc_init(&a);
   for (int i = 0; i < 32; i++) mhlik_softplus_acc_add(&a, x[(size_t)g * 32 + i]);
+  if (a.lin > MHLIK_SOFTPLUS_OVERFLOW)
+    for (int i = 0; i < 32; i++) mhlik_softplus_acc_flag_overflow(&a, x[(size_t)g * 32 + i]);
   f[g] = mhlik_softplus_acc_neg_sum(&a);
 }
 int main()
