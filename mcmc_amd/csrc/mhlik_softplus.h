@@ -33,24 +33,47 @@
 #define MHLIK_SP static inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/* A coefficient as an opaque scalar-register value: v_fma_f64 takes it as its one scalar operand.  Left to
+ * itself the compiler keeps the coefficients in vector registers and forms every Horner step as a copy of the
+ * coefficient plus v_fmac_f64 -- a third more instructions for the same bits. */
+#define MHLIK_SP_COEF(name, value) \
+  double name = value;             \
+  __asm__("" : "+s"(name))
+#else
+#define MHLIK_SP_COEF(name, value) const double name = value
+#endif
+
 /* e^-u for u >= 0: x = n ln2 + r, |r| <= ln2/2 (two-part ln2), degree-12 Taylor polynomial, scaled by 2^n with
  * ldexp; < 3e-16 relative; u > 745 underflows to 0. */
 MHLIK_SP double mhlik_exp_neg(double u)
 {
+  MHLIK_SP_COEF(log2e, 1.4426950408889634074);
+  MHLIK_SP_COEF(ln2hi, -6.93147180369123816490e-01); /* ln2 high part: fn * hi is exact */
+  MHLIK_SP_COEF(ln2lo, -1.90821492927058770002e-10); /* ln2 low part */
+  MHLIK_SP_COEF(c12, 2.08767569878680989792e-09);    /* 1/12! */
+  MHLIK_SP_COEF(c11, 2.50521083854417187751e-08);
+  MHLIK_SP_COEF(c10, 2.75573192239858906526e-07);
+  MHLIK_SP_COEF(c9, 2.75573192239858906526e-06);
+  MHLIK_SP_COEF(c8, 2.48015873015873015873e-05);
+  MHLIK_SP_COEF(c7, 1.98412698412698412698e-04);
+  MHLIK_SP_COEF(c6, 1.38888888888888888889e-03);
+  MHLIK_SP_COEF(c5, 8.33333333333333333333e-03);
+  MHLIK_SP_COEF(c4, 4.16666666666666666667e-02);
+  MHLIK_SP_COEF(c3, 1.66666666666666666667e-01);     /* 1/3! */
   const double t = -u;
-  const double fn = rint(t * 1.4426950408889634074);
-  double r = fma(fn, -6.93147180369123816490e-01, t); /* ln2 high part: fn * hi is exact */
-  r = fma(fn, -1.90821492927058770002e-10, r);        /* ln2 low part */
-  double p = 2.08767569878680989792e-09;              /* 1/12! */
-  p = fma(p, r, 2.50521083854417187751e-08);          /* 1/11! */
-  p = fma(p, r, 2.75573192239858906526e-07);          /* 1/10! */
-  p = fma(p, r, 2.75573192239858906526e-06);          /* 1/9!  */
-  p = fma(p, r, 2.48015873015873015873e-05);          /* 1/8!  */
-  p = fma(p, r, 1.98412698412698412698e-04);          /* 1/7!  */
-  p = fma(p, r, 1.38888888888888888889e-03);          /* 1/6!  */
-  p = fma(p, r, 8.33333333333333333333e-03);          /* 1/5!  */
-  p = fma(p, r, 4.16666666666666666667e-02);          /* 1/4!  */
-  p = fma(p, r, 1.66666666666666666667e-01);          /* 1/3!  */
+  const double fn = rint(t * log2e);
+  double r = fma(fn, ln2hi, t);
+  r = fma(fn, ln2lo, r);
+  double p = fma(c12, r, c11);
+  p = fma(p, r, c10);
+  p = fma(p, r, c9);
+  p = fma(p, r, c8);
+  p = fma(p, r, c7);
+  p = fma(p, r, c6);
+  p = fma(p, r, c5);
+  p = fma(p, r, c4);
+  p = fma(p, r, c3);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -76,15 +99,23 @@ MHLIK_SP double mhlik_neg_softplus(double x)
   const double z = num / den;
 #endif
   const double z2 = z * z;
-  double q = 1.0 / 19.0;
-  q = fma(q, z2, 1.0 / 17.0);
-  q = fma(q, z2, 1.0 / 15.0);
-  q = fma(q, z2, 1.0 / 13.0);
-  q = fma(q, z2, 1.0 / 11.0);
-  q = fma(q, z2, 1.0 / 9.0);
-  q = fma(q, z2, 1.0 / 7.0);
-  q = fma(q, z2, 1.0 / 5.0);
-  q = fma(q, z2, 1.0 / 3.0);
+  MHLIK_SP_COEF(a19, 1.0 / 19.0);
+  MHLIK_SP_COEF(a17, 1.0 / 17.0);
+  MHLIK_SP_COEF(a15, 1.0 / 15.0);
+  MHLIK_SP_COEF(a13, 1.0 / 13.0);
+  MHLIK_SP_COEF(a11, 1.0 / 11.0);
+  MHLIK_SP_COEF(a9, 1.0 / 9.0);
+  MHLIK_SP_COEF(a7, 1.0 / 7.0);
+  MHLIK_SP_COEF(a5, 1.0 / 5.0);
+  MHLIK_SP_COEF(a3, 1.0 / 3.0);
+  double q = fma(a19, z2, a17);
+  q = fma(q, z2, a15);
+  q = fma(q, z2, a13);
+  q = fma(q, z2, a11);
+  q = fma(q, z2, a9);
+  q = fma(q, z2, a7);
+  q = fma(q, z2, a5);
+  q = fma(q, z2, a3);
   q = q * z2;                           /* atanh(z)/z - 1 */
   double l = fma(z + z, q, z + z);      /* 2 atanh(z) */
   l += big ? 6.93147180559945309417e-01 : 0.0;
@@ -131,17 +162,6 @@ MHLIK_SP double mhlik_neg_softplus(double x)
 /* e^-u for u >= 0, the product form's factor: as mhlik_exp_neg with a degree-10 minimax polynomial (c0 = c1 = 1;
  * relative error 2.9e-16 equi-rippled over |r| <= ln2/2, from a Remez exchange in 60-digit arithmetic) instead
  * of the degree-12 Taylor one; < 5e-16 relative with the roundings; u > 745 underflows to 0; NaN stays NaN. */
-#if defined(__HIP_DEVICE_COMPILE__)
-/* A coefficient as an opaque scalar-register value: v_fma_f64 takes it as its one scalar operand.  Left to
- * itself the compiler keeps the coefficients in vector registers and forms every Horner step as a copy of the
- * coefficient plus v_fmac_f64 -- a third more instructions for the same bits. */
-#define MHLIK_SP_COEF(name, value) \
-  double name = value;             \
-  __asm__("" : "+s"(name))
-#else
-#define MHLIK_SP_COEF(name, value) const double name = value
-#endif
-
 MHLIK_SP double mhlik_exp_neg_fast(double u)
 {
   MHLIK_SP_COEF(log2e, 1.4426950408889634074);
