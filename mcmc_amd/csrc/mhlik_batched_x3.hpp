@@ -141,7 +141,7 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
 #pragma unroll
       for (int n = 0; n < NB; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  V4 x[8], y[8], z[NBUF == 3 ? 8 : 1];
+  V4 ring[NBUF][8]; // NBUF blocks in flight (statically indexed: they live in registers)
   auto load_block = [&](V4 (&buf)[8], int64_t tile, int pass, int kb) {
     const float *ubase = X + tile * tile_stride + pass * 256 + wave * 64;
     if (EXP & 8) { // lab: the same bytes as 1 KB-contiguous wave loads (column (pass*nkb + kb)*8 + u, rows 256*wave + 4*lane)
@@ -315,41 +315,48 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
     advance(w);
   };
   zero_acc();
-  if (EXP & 2) {
+  static_assert(NBUF >= 2 && NBUF <= 8, "two to eight load buffers");
+  if constexpr (NBUF == 2) { // the production shape, written out (the general form below costs it registers)
+    V4(&x)[8] = ring[0];
+    V4(&y)[8] = ring[1];
+    if (EXP & 2) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) x[u] = y[u] = V4{1.f + lane, 2.f, 3.f, 4.f + u};
-    advance(l);
-    advance(l);
-  } else {
-    load_block(x, l.tile, l.pass, l.kb);
-    advance(l);
-    load_block(y, l.tile, l.pass, l.kb);
-    advance(l);
-    if constexpr (NBUF == 3) {
-      load_block(z, l.tile, l.pass, l.kb);
+      for (int u = 0; u < 8; u++) x[u] = y[u] = V4{1.f + lane, 2.f, 3.f, 4.f + u};
+      advance(l);
+      advance(l);
+    } else {
+      load_block(x, l.tile, l.pass, l.kb);
+      advance(l);
+      load_block(y, l.tile, l.pass, l.kb);
       advance(l);
     }
-  }
-  if constexpr (NBUF == 3) { // three blocks in flight; total >= 4
-    int64_t b = 0;
-    for (; b + 6 <= total; b += 3) {
-      finish(x, true);
-      finish(y, true);
-      finish(z, true);
-    }
-    const int rem = (int)(total - b); // 3, 4 or 5 blocks left, rem - 3 of them not yet requested
-    finish(x, rem > 3);
-    finish(y, rem > 4);
-    finish(z, false);
-    if (rem > 3) finish(x, false);
-    if (rem > 4) finish(y, false);
-  } else {
     for (int64_t b = 0; b + 3 < total; b += 2) {
       finish(x, true);
       finish(y, true);
     }
     finish(x, false);
     finish(y, false);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NBUF; b++) { // total >= 4: with more buffers than blocks the surplus requests are skipped
+      if (EXP & 2) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) ring[b][u] = V4{1.f + lane, 2.f, 3.f, 4.f + u};
+      } else if (b < total) {
+        load_block(ring[b], l.tile, l.pass, l.kb);
+      }
+      advance(l);
+    }
+    // full rounds while every finished block still has a successor NBUF blocks ahead, then the last NBUF .. 2 NBUF - 1
+    int64_t done = 0;
+    for (; done + 2 * NBUF <= total; done += NBUF) {
+#pragma unroll
+      for (int b = 0; b < NBUF; b++) finish(ring[b], true);
+    }
+    const int rem = (int)(total - done);
+#pragma unroll
+    for (int i = 0; i < 2 * NBUF - 1; i++)
+      if (i < rem) finish(ring[i % NBUF], i + NBUF < rem);
   }
 }
 
@@ -357,7 +364,7 @@ __device__ __forceinline__ void batched_x3_stream(const float *__restrict__ X, i
 // g, g + gridDim.x, ...  NB = number of 16-chain blocks (1..4).  theta_dev: the LDS image
 // (d_pad/32 * NB * 3 * 64 * 16 bytes).  Partials as lik_batched_f32_kernel: partials[chain*pstride + tile].
 template <int NB, int TERMS, int EXP = 0, int NBUF = 2>
-__global__ __launch_bounds__(kBlock, 2) void lik_batched_x3_kernel(const float *__restrict__ X, TileGeom g,
+__global__ __launch_bounds__(kBlock, NBUF > 3 ? 1 : 2) void lik_batched_x3_kernel(const float *__restrict__ X, TileGeom g,
                                                                    const int32_t *__restrict__ tile_valid,
                                                                    const u32x4 *__restrict__ theta_dev, int d_pad,
                                                                    double *__restrict__ partials, int64_t pstride,

@@ -68,7 +68,17 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
   size_t lds3 = img3.size() * 4 + sizeof(double) * 4 * 4 * 64;
   (void)flops; (void)th32;
+#define RUNN(NBUFV, label) { auto k = lik_batched_x3_kernel<4, 6, 0, NBUFV>; \
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
+    CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
+#define RUNNL(NBUFV, label) { auto k = lik_batched_x3_kernel<4, 6, 5, NBUFV>; \
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
+    CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
   for (int round = 0; round < 2; round++) {
+    RUNN(4, "one wave per SIMD, four load buffers")
+    RUNNL(4, "one wave per SIMD, four buffers, loads only")
     RUN(0, "production")
     RUN(256, "production + workgroup barrier per k-block")
     RUN(128, "exp + log per element (the round-1 epilogue)")
