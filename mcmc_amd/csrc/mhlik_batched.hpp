@@ -361,6 +361,9 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
     // tile row = row0 + (m>>1)*32 + 2*i + (m&1).  Only the last tile of a shard is ragged: the full case is
     // straight-line code with no per-element predicate.
     const bool full = row0 + 64 <= valid;
+    mhlik_softplus_acc before[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) before[n] = pacc[n];
     auto epilogue = [&](auto full_tag) {
       constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
@@ -384,17 +387,19 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
     else
       epilogue(std::false_type{});
     if constexpr ((EXP & 8) != 0) {
-      // the adds do not test for the reference's overflow to -inf above 709.78: a group whose linear part got
-      // there is looked over while its elements are still in the accumulators
+      // the fast adds leave out the tests for the reference's overflow to -inf above 709.78 and for arguments
+      // beyond the range reduction's reach: a group that looks suspect is redone from its state before the pass
+      // while its elements are still in the accumulators
 #pragma unroll
       for (int n = 0; n < NB; n++)
-        if (pacc[n].lin > MHLIK_SOFTPLUS_OVERFLOW) {
+        if (mhlik_softplus_acc_suspect(&pacc[n])) {
+          pacc[n] = before[n];
 #pragma unroll
           for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
               if (full || (row0 + (m >> 1) * 32 + 2 * (kk + 4 * r) + (m & 1) < valid))
-                mhlik_softplus_acc_flag_overflow(&pacc[n], acc[m][n][r]);
+                mhlik_softplus_acc_add_safe(&pacc[n], acc[m][n][r]);
         }
     }
   }

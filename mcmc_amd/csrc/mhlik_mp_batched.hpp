@@ -311,6 +311,18 @@ __device__ __noinline__ MpbTerms mpb_pair_terms(float af, double ad, double eps,
   return t;
 }
 
+// The common case inline: a dark pair under re-examination whose u = B(1 + e^x) - 1 is small (always, away from the
+// far tails).  Same float sigmoid, same series as mpb_pair_terms; e^x from mhlik_exp_fast (5e-16 relative, i.e. at
+// most 5e-16 absolute on u, which is of order 1e-7).  Returns false when the pair needs mpb_pair_terms instead.
+__device__ __forceinline__ bool mpb_dark_term(float af, double ad, double eps, double &rs)
+{
+  const float sig_s = mhlik_sigmoidf_det(af);
+  const double Bd = (double)sig_s - eps;
+  const double u = fma(Bd, mhlik_exp_fast(ad), Bd - 1.0);
+  rs = u * (1.0 - u * (0.5 - u * (1.0 / 3.0 - u * 0.25)));
+  return fabs(u) < 0x1p-10; // false for NaN
+}
+
 // The rows of data block b against the theta of G chains c[0..G): per chain
 // the wave totals  lb = sum log(L - B)  (bright at entry)  and
 // rs = sum (log B - log L).  thd / thf: Theta as [chain][d_pad] doubles /
@@ -708,9 +720,14 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
 #pragma unroll
               for (int r = 0; r < 4; r++) {
                 if (first + 4 * (4 * ag + r) + m < covered) {
-                  const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, bright);
-                  s_rs += t.rs;
-                  if (bright) s_lb += t.lb;
+                  double rs_fast;
+                  if (!bright && mpb_dark_term(af[m][r], ad[m][r], p.eps, rs_fast)) {
+                    s_rs += rs_fast;
+                  } else {
+                    const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, bright);
+                    s_rs += t.rs;
+                    if (bright) s_lb += t.lb;
+                  }
                 }
               }
           }

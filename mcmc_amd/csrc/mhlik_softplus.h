@@ -82,7 +82,8 @@ MHLIK_SP double mhlik_exp_neg(double u)
 
 MHLIK_SP double mhlik_neg_softplus(double x)
 {
-  const double y = mhlik_exp_neg(fabs(x));
+  const double ax = fabs(x);
+  const double y = mhlik_exp_neg(!(ax > 800.0) ? ax : 800.0); /* beyond ~1e25 the reduction would lose r; NaN stays NaN */
 
   /* log1p(y), y in [0, 1] */
   const int big = y > 0.41421356237309504880; /* 1 + y > sqrt(2) */
@@ -151,18 +152,19 @@ MHLIK_SP double mhlik_neg_softplus(double x)
  * where the EXACT mode (which keeps tiny terms to relative accuracy) is the
  * better of the two and also differs from the reference's formula.
  * Overflow: the reference's formula gives -inf above x = 709.78.  The adds do
- * not test for it; a group whose linear part exceeds that value is looked
- * over again with mhlik_softplus_acc_flag_overflow (the kernel does so while
- * the elements are still in registers).
+ * not test for it, nor for arguments so large that the range reduction breaks
+ * down; a group whose linear part exceeds that value or whose product has
+ * left its range is redone with mhlik_softplus_acc_add_safe (the kernel does
+ * so while the elements are still in registers).
  * tests/test_softplus.py states a lane's work on the host and measures
  * accuracy and bias against 80-bit sums.
  * -------------------------------------------------------------------------*/
 #define MHLIK_SOFTPLUS_OVERFLOW 709.782712893383973096
 
-/* e^-u for u >= 0, the product form's factor: as mhlik_exp_neg with a degree-10 minimax polynomial (c0 = c1 = 1;
- * relative error 2.9e-16 equi-rippled over |r| <= ln2/2, from a Remez exchange in 60-digit arithmetic) instead
- * of the degree-12 Taylor one; < 5e-16 relative with the roundings; u > 745 underflows to 0; NaN stays NaN. */
-MHLIK_SP double mhlik_exp_neg_fast(double u)
+/* e^t for any t: as mhlik_exp_neg with a degree-10 minimax polynomial (c0 = c1 = 1; relative error 2.9e-16
+ * equi-rippled over |r| <= ln2/2, from a Remez exchange in 60-digit arithmetic) instead of the degree-12 Taylor
+ * one; < 5e-16 relative with the roundings; underflows to 0 below -745, +inf above 709.8, NaN stays NaN. */
+MHLIK_SP double mhlik_exp_fast(double t)
 {
   MHLIK_SP_COEF(log2e, 1.4426950408889634074);
   MHLIK_SP_COEF(ln2hi, -6.93147180369123816490e-01);
@@ -176,7 +178,6 @@ MHLIK_SP double mhlik_exp_neg_fast(double u)
   MHLIK_SP_COEF(c4, 0x1.55555555890c1p-5);
   MHLIK_SP_COEF(c3, 0x1.55555555507c5p-3);
   MHLIK_SP_COEF(c2, 0x1.ffffffffffed2p-2);
-  const double t = -u;
   const double fn = rint(t * log2e);
   double r = fma(fn, ln2hi, t);
   r = fma(fn, ln2lo, r);
@@ -190,8 +191,15 @@ MHLIK_SP double mhlik_exp_neg_fast(double u)
   p = fma(p, r, c2);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)fn);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ldexp(p, (int)fn); /* v_cvt_i32_f64 saturates (NaN -> 0): p 2^n is 0, +inf or NaN as it should be */
+#else
+  return ldexp(p, fn != fn ? 0 : fn > 4000.0 ? 4000 : fn < -4000.0 ? -4000 : (int)fn);
+#endif
 }
+
+/* e^-u for u >= 0, the product form's factor */
+MHLIK_SP double mhlik_exp_neg_fast(double u) { return mhlik_exp_fast(-u); }
 
 typedef struct {
   double lin;  /* sum of max(x, 0); +inf once an x above 709.78 was flagged (the reference's formula overflows there) */
@@ -216,10 +224,23 @@ MHLIK_SP void mhlik_softplus_acc_add(mhlik_softplus_acc *a, double x)
   a->prod = fma(a->prod, mhlik_exp_neg_fast(fabs(x)), a->prod);
 }
 
-/* second look at an element of a group whose lin exceeded MHLIK_SOFTPLUS_OVERFLOW */
-MHLIK_SP void mhlik_softplus_acc_flag_overflow(mhlik_softplus_acc *a, double x)
+/* The same, with the tests the fast add leaves out: +inf in lin above the reference's overflow point, and no
+ * trip through the range reduction for |x| beyond the underflow point (from ~1e25 on its r is garbage and the
+ * polynomial overflows).  A group is redone with this from its saved state when mhlik_softplus_acc_suspect()
+ * says so -- the kernel does that per pass, while the elements are still in the accumulators. */
+MHLIK_SP void mhlik_softplus_acc_add_safe(mhlik_softplus_acc *a, double x)
 {
-  if (x > MHLIK_SOFTPLUS_OVERFLOW) a->lin = HUGE_VAL;
+  a->lin += x > MHLIK_SOFTPLUS_OVERFLOW ? HUGE_VAL : (x > 0.0 ? x : 0.0);
+  const double ax = fabs(x);
+  const double y = ax <= 745.2 ? mhlik_exp_neg_fast(ax) : (ax != ax ? ax : 0.0);
+  a->prod = fma(a->prod, y, a->prod);
+}
+
+/* after at most 32 fast adds to a state that was not suspect: lin may have passed an x above the overflow
+ * point, or prod has left [1, 2^40] (an infinite or NaN factor) */
+MHLIK_SP int mhlik_softplus_acc_suspect(const mhlik_softplus_acc *a)
+{
+  return !(a->lin <= MHLIK_SOFTPLUS_OVERFLOW) || !(a->prod <= 0x1p40);
 }
 
 /* a += b: the elements of both groups (at most ~1000 elements altogether: the product must stay finite) */

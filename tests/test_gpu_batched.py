@@ -194,21 +194,29 @@ def test_batched_begin_end_equals_the_blocking_call(dtype):
         assert np.array_equal(lk.loglik_batched(Theta_copy, dtype=dtype), want)  # and the context is usable again
 
 
-def test_batched_overflow_column():
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_batched_overflow_column(mode):
+    """Dots at and far beyond the ends of exp's range, in both epilogues of the double pass: -inf above 709.78 like
+    the reference's formula, exactly 0 below the underflow point -- also for |x| = 1e30, where a range reduction
+    x - n ln2 has lost every bit of r."""
     from mcmc_amd import Likelihood
 
     N, d = 2000, 2
     X = np.zeros((N, d), order="F")
     X[:, 0] = 1.0
     X[:, 1] = np.linspace(-1, 1, N)
-    Theta = np.array([[800.0, 0.0], [0.1, 0.2], [-800.0, 0.0]])
+    Theta = np.array([[800.0, 0.0], [0.1, 0.2], [-800.0, 0.0], [1e30, 0.0], [-1e30, 0.0], [-3e300, 0.0]])
     with Likelihood(N, d) as lk:
         lk.upload(X)
+        lk.set_batched_f64_mode(mode)
         got = lk.loglik_batched(Theta)
     want = _oracle_batched(X, Theta)
     assert got[0] == want[0] == -np.inf
     assert abs(got[1] - want[1]) <= 1e-10 * abs(want[1])
     assert got[2] == want[2] == 0.0
+    assert got[3] == want[3] == -np.inf
+    assert got[4] == want[4] == 0.0
+    assert got[5] == want[5] == 0.0
 
 
 def test_multichain_sampler_reproduces_single_chains():

@@ -19,8 +19,10 @@ __global__ void kgroup(const double *x, double *f, int ngroups)
   mhlik_softplus_acc a;
   mhlik_softplus_acc_init(&a);
   for (int i = 0; i < 32; i++) mhlik_softplus_acc_add(&a, x[(size_t)g * 32 + i]);
-  if (a.lin > MHLIK_SOFTPLUS_OVERFLOW)
-    for (int i = 0; i < 32; i++) mhlik_softplus_acc_flag_overflow(&a, x[(size_t)g * 32 + i]);
+  if (mhlik_softplus_acc_suspect(&a)) {
+    mhlik_softplus_acc_init(&a);
+    for (int i = 0; i < 32; i++) mhlik_softplus_acc_add_safe(&a, x[(size_t)g * 32 + i]);
+  }
   f[g] = mhlik_softplus_acc_neg_sum(&a);
 }
 int main()
