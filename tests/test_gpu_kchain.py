@@ -149,3 +149,37 @@ def test_mp_device_loop_equals_host_loop(shared, f32_mode):
     assert np.array_equal(dev["bright"], host["bright"])
     assert np.array_equal(z_dev, z_host)
     assert 0 < dev["accepted"].sum() < K * Ns
+
+
+@pytest.mark.parametrize("mode,dtype", [(1, np.float64), (2, np.float32)])
+def test_kchain_over_forced_rccl_is_bitwise_equal(monkeypatch, mode, dtype):
+    """The K-chain loop as N ranks run it -- separate segment-sum, in-stream ncclAllReduce of the K x segments slots,
+    step kernel, Theta image kernel -- on a one-rank communicator (MHLIK_FORCE_COMM=1), against the fused
+    single-GPU loop: same likelihoods, decisions and samples, bit for bit."""
+    from mcmc_amd import Likelihood
+
+    N, d, K, n = 60_000, 12, 9, 40
+    rng = np.random.default_rng(8)
+    theta0 = rng.normal(0, 0.05, (K, d))
+    inc = rng.normal(0, 0.004, (n, K, d))
+    logu = np.log(rng.uniform(size=(n, K)))
+
+    def run(force):
+        with Likelihood(N, d, precision=3, device=0) as lk:
+            lk.fill_synthetic(17)
+            if force:
+                lk.comm_init(Likelihood.make_comm_id())
+                assert lk.comm_ranks() == 1
+            cp = lk.kchain_begin(theta0, 10.0, mode=mode)
+            out = lk.kchain_run(inc, logu)
+            state, cpe = lk.kchain_state(K)
+            return cp, out, state, cpe
+
+    cp0, plain, st0, ce0 = run(False)
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    cp1, forced, st1, ce1 = run(True)
+    assert np.array_equal(cp0, cp1)
+    for k in ("samples", "lik", "ratio", "accepted"):
+        assert np.array_equal(plain[k], forced[k]), k
+    assert np.array_equal(st0, st1) and np.array_equal(ce0, ce1)
+    assert 0 < plain["accepted"].sum() < n * K
