@@ -65,3 +65,69 @@ def test_random_shape(N, d, K, seg, scale, seed):
         err = np.abs(v - wantK) / np.maximum(np.abs(wantK), 1e-300)
         assert np.all(err <= rel + (1e-6 / np.maximum(np.abs(wantK), 1e-300) if rel > 1e-9 else 0)), (name, err.max())
     assert abs(fast[0] - got) <= tol and abs(exact[0] - got) <= tol
+
+
+def _mp_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        block_rows = int(rng.choice([64, 128, 256, 512, 1024]))
+        N = int(rng.integers(block_rows, 40 * block_rows if block_rows <= 256 else 12 * block_rows))
+        if i % 3 == 0:
+            N = (N // block_rows) * block_rows  # no ragged last block
+        d = int(rng.choice([1, 3, 8, 16, 17, 40, 64]))
+        F = int(rng.choice([2, 3, 10, 16]))
+        K = int(rng.choice([1, 5, 16, 33, 64]))
+        shared = bool(i % 2)
+        out.append((N, d, block_rows, F, K, shared, int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("N,d,block_rows,F,K,shared,seed", _mp_cases(14, 77))
+def test_random_mixed_precision_sequences(N, d, block_rows, F, K, shared, seed):
+    """Mixed precision (mcmc_mp.cu:28-200,475-552) on random geometries: a sequence of calls -- the indicators evolve
+    from call to call -- of the single-chain path against the oracle (identical bright / dark counts, value within
+    2e-6), and of the K-chain path against K single-chain contexts' worth of oracle sequences (chain k = the oracle's
+    sequence with chain k's theta, phase and seed; both float modes)."""
+    import ctypes as C
+
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+    from test_gpu_mp import _oracle_mp
+
+    rng = np.random.default_rng(seed)
+    X = synthetic_host(seed, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    blocks = (N + block_rows - 1) // block_rows
+    eps, calls = 1.7e-7, 5
+    thetas = rng.normal(0, 0.4 / np.sqrt(d), (calls, K, d))
+    phases = rng.integers(0, F, (calls, K))
+    if shared:
+        phases[:] = phases[:, :1]
+    seeds = (1000 + np.arange(K)).astype(np.uint64)
+    # oracle: one sequence per chain
+    want = np.empty((calls, K))
+    wb = np.empty((calls, K), dtype=np.int64)
+    for k in range(K if K <= 5 else 3):  # the oracle's scalar loop is slow: all chains when few, else three of them
+        z = np.ones(blocks, dtype=np.int8)
+        for c in range(calls):
+            want[c, k], wb[c, k], _ = _oracle_mp(X, Xf, thetas[c, k], block_rows, blocks, F, int(phases[c, k]),
+                                                 int(seeds[k]), c, eps, z)
+    checked = range(K if K <= 5 else 3)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.upload(X)
+        lk.upload(Xf)
+        lk.mp_reset(block_rows, blocks)
+        for c in range(calls):  # chain 0 through the single-chain entry point
+            got, gb, gd = lk.mp_loglik(thetas[c, 0], block_rows, blocks, F, int(phases[c, 0]), int(seeds[0]), c, eps)
+            assert gb == wb[c, 0] and gb + gd == blocks, (c, gb, gd, wb[c, 0])
+            assert abs(got - want[c, 0]) <= 2e-6 * abs(want[c, 0]) + 1e-9
+        for mode in ("exact", "split"):
+            lk.set_batched_f32_mode(mode)
+            lk.mp_reset_batched(block_rows, blocks, K)
+            for c in range(calls):
+                vals, nb, nd = lk.mp_loglik_batched(thetas[c], F, phases[c], seeds, c, eps)
+                for k in checked:
+                    assert nb[k] == wb[c, k] and nb[k] + nd[k] == blocks, (mode, c, k, nb[k], wb[c, k])
+                    tol = 2e-6 if mode == "exact" else 2e-5
+                    assert abs(vals[k] - want[c, k]) <= tol * abs(want[c, k]) + 1e-9, (mode, c, k, vals[k], want[c, k])
