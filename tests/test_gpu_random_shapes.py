@@ -131,3 +131,46 @@ def test_random_mixed_precision_sequences(N, d, block_rows, F, K, shared, seed):
                     assert nb[k] == wb[c, k] and nb[k] + nd[k] == blocks, (mode, c, k, nb[k], wb[c, k])
                     tol = 2e-6 if mode == "exact" else 2e-5
                     assert abs(vals[k] - want[c, k]) <= tol * abs(want[c, k]) + 1e-9, (mode, c, k, vals[k], want[c, k])
+
+
+def _chain_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        N = int(rng.choice([1, 511, 513, 2000, 7777, 30000]))
+        d = int(rng.choice([1, 3, 16, 33, 64]))
+        Ns = int(rng.choice([1, 17, 130, 400]))
+        burnin = int(rng.choice([1, 2, 60]))
+        step = float(rng.choice([0.02, 0.3, 2.0]))  # from every proposal accepted to nearly none
+        out.append((N, d, Ns, burnin, step, int(rng.integers(1 << 20))))
+    return out
+
+
+@pytest.mark.parametrize("N,d,Ns,burnin,step,seed", _chain_cases(12, 5))
+def test_random_chains_reproduce_the_oracle(N, d, Ns, burnin, step, seed):
+    """gpu_sampler (mcmc_gpu.cu:20-128) and chain 0 / chain K-1 of the K-chain sampler against the oracle's cpu_sampler
+    on random sizes, lengths and step sizes: accept / reject sequence, samples and burn-in rows identical."""
+    from mcmc_amd import Likelihood, samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    X = synthetic_host(seed, N, d)
+    rwsd = 2.38 / np.sqrt(d) * step
+    ref = O.cpu_sampler(X, seed, Ns, burnin, rwsd)
+    got = S.gpu_sampler(X, seed, Ns, burnin, rwsd)
+    assert np.array_equal(ref["trace"]["accept"], got["trace"]["accept"])
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert np.array_equal(ref["burn"], got["burn"])
+    if len(ref["trace"]):
+        lik_r, lik_g = ref["trace"]["lik"], got["trace"]["lik"]
+        fin = np.isfinite(lik_r)
+        assert np.array_equal(fin, np.isfinite(lik_g))
+        assert np.all(np.abs(lik_r[fin] - lik_g[fin]) <= 1e-10 * np.abs(lik_r[fin]))
+    K = 1 + seed % 7
+    seeds = [seed + 3 * k for k in range(K)]
+    with Likelihood(N, d) as lk:
+        lk.upload(X)
+        many = S.multichain_sampler(lk, seeds, Ns, burnin, rwsd)
+    assert np.array_equal(ref["samples"], many["samples"][0])
+    last = O.cpu_sampler(X, seeds[-1], Ns, burnin, rwsd)
+    assert np.array_equal(last["samples"], many["samples"][K - 1])
+    assert np.array_equal(last["burn"][1:], many["burn"][K - 1][1:])
