@@ -314,7 +314,7 @@ __device__ __noinline__ MpbTerms mpb_pair_terms(float af, double ad, double eps,
 // The common case inline: a dark pair under re-examination whose u = B(1 + e^x) - 1 is small (always, away from the
 // far tails).  Same float sigmoid, same series as mpb_pair_terms; e^x from mhlik_exp_fast (5e-16 relative, i.e. at
 // most 5e-16 absolute on u, which is of order 1e-7).  Returns false when the pair needs mpb_pair_terms instead.
-__device__ __forceinline__ bool mpb_dark_term(float af, double ad, double eps, double &rs)
+__device__ __forceinline__ bool mpb_reexamined_term(float af, double ad, double eps, double &rs)
 {
   const float sig_s = mhlik_sigmoidf_det(af);
   const double Bd = (double)sig_s - eps;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
               for (int r = 0; r < 4; r++) {
                 if (first + 4 * (4 * ag + r) + m < covered) {
                   double rs_fast;
-                  if (!bright && mpb_dark_term(af[m][r], ad[m][r], p.eps, rs_fast)) {
+                  if (!bright && mpb_reexamined_term(af[m][r], ad[m][r], p.eps, rs_fast)) {
                     s_rs += rs_fast;
                   } else {
                     const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, bright);

@@ -154,7 +154,7 @@ int main(void){
 def test_exp_fast_host_accuracy():
     """mhlik_exp_fast (the factor of the product-form epilogue and of the dense mixed-precision correction): below
     5e-16 relative over the normal range against 80-bit expl; exact at 0; 0 / +inf / NaN at the ends (arguments beyond ~1e25, where the two-part reduction
-    loses r, are the callers' business: mhlik_softplus_acc_add_safe, the mpb_dark_term fallback)."""
+    loses r, are the callers' business: mhlik_softplus_acc_add_safe, the mpb_reexamined_term fallback)."""
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "t.c")
         open(c, "w").write(EXP_SRC)
