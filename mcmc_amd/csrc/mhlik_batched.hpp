@@ -286,6 +286,26 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
     mhlik_softplus_acc_init(&pacc[n]);
   }
 
+  const int nfull = d / (4 * KU);
+  V2 n0[KU], n1[KU]; // the k-batch in flight
+  // the first k-batch of a pass: requested before the previous pass's epilogue, so that it lands under it
+  auto first_batch = [&](int pass) {
+    if (nfull > 0 && !(EXP & 2)) {
+      const double *rb = tbase + wave * 128 + pass * 64 + 2 * arow;
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const double *col = rb + (int64_t)(4 * u + kk) * g.col_stride;
+        n0[u] = load16<double, true>(col);
+        n1[u] = load16<double, true>(col + 32);
+      }
+    }
+  };
+  if (EXP & 2) {
+#pragma unroll
+    for (int u = 0; u < KU; u++) n0[u] = n1[u] = V2{1.0 + lane, 2.0 + u};
+  }
+  first_batch(0);
+
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
     const int row0 = wave * 128 + pass * 64;
@@ -299,16 +319,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         for (int r = 0; r < 4; r++) acc[m][n][r] = 0.0;
 
     int j0 = 0;
-    const int nfull = d / (4 * KU);
-    V2 a0[KU], a1[KU], n0[KU], n1[KU];
-    if (nfull > 0) {
-#pragma unroll
-      for (int u = 0; u < KU; u++) {
-        const double *col = rbase + (int64_t)(4 * u + kk) * g.col_stride;
-        n0[u] = load16<double, true>(col);
-        n1[u] = load16<double, true>(col + 32);
-      }
-    }
+    V2 a0[KU], a1[KU];
     for (int bt = 0; bt < nfull; bt++, j0 += 4 * KU) {
 #pragma unroll
       for (int u = 0; u < KU; u++) {
@@ -356,6 +367,9 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         acc[3][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b, acc[3][n], 0, 0, 0);
       }
     }
+
+    if (pass == 0) first_batch(1);
+    __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the epilogue
 
     // accumulator (m, n, r) of lane l: A-row i = (l>>4) + 4*r, chain n*16 + (l&15);
     // tile row = row0 + (m>>1)*32 + 2*i + (m&1).  Only the last tile of a shard is ragged: the full case is
