@@ -265,6 +265,17 @@ int mhlik_mp_loglik_batched(mhlik_ctx *ctx, const mhlik_mp_batch *st, const doub
 int mhlik_mp_loglik_batched_begin(mhlik_ctx *ctx, const mhlik_mp_batch *st, const double *Theta);
 int mhlik_mp_loglik_batched_end(mhlik_ctx *ctx, double *out, int32_t *bright_blocks, int32_t *dark_blocks);
 
+/* Row shards for the K-chain mixed-precision calls (no counterpart in the reference): as for mhlik_mp_loglik, a
+ * context with several segments (config.segment_align a multiple of 1024) and world > 1 evaluates the data blocks
+ * of its own rows; per chain and segment the three sums (double sum over blocks bright at entry, float sum over dark
+ * rows, bright count) are all-reduced in the stream and added in segment order on the device -- bit-identical for
+ * every world that divides `segments` (with segments = 1 the bits of the unsharded path).  The indicators a rank
+ * keeps (mhlik_mp_indicators_batched) are those of its own blocks; the others stay at their reset value.  Without
+ * a communicator the call returns this rank's share, and mhlik_mp_last_slots_batched hands out the 4*K*segments
+ * slots of the last evaluation, slots[(k*4 + i)*segments + g], i = 0 double sum, 1 float sum, 2 bright count
+ * (3 unused), to be summed over the ranks by the caller. */
+int mhlik_mp_last_slots_batched(mhlik_ctx *ctx, int32_t K, double *slots);
+
 /* Copy the indicators to the host as [K][blocks] (tests / diagnostics). */
 int mhlik_mp_indicators_batched(mhlik_ctx *ctx, int8_t *z);
 

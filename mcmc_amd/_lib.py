@@ -138,6 +138,7 @@ _SIGS = [
     ("mhlik_mp_loglik", C.c_int, [_P, C.POINTER(MpState), _P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mhlik_mp_bound", C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("mhlik_mp_last_slots", C.c_int, [_P, _P]),
+    ("mhlik_mp_last_slots_batched", C.c_int, [_P, C.c_int32, _P]),
     ("mhlik_mp_reset_batched", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     ("mhlik_mp_loglik_batched", C.c_int, [_P, C.POINTER(MpBatch), _P, _P, _P, _P]),
     ("mhlik_mp_loglik_batched_begin", C.c_int, [_P, C.POINTER(MpBatch), _P]),

@@ -219,6 +219,9 @@ struct mhlik_ctx {
   double *mpb_theta = nullptr;  // [64][d] row-major
   float *mpb_thetaf = nullptr;
   double *mpb_res = nullptr, *mpb_res_dev = nullptr; // pinned host [64][4] and its device view
+  void *mpb_segtab = nullptr;   // device MpbSeg[local segments]: each segment's data blocks
+  double *mpb_slots_send = nullptr, *mpb_slots_recv = nullptr; // device [64*4][nseg], zero outside the local segments
+  int mpb_seg_groups = 0;
 
   void *stats_buf = nullptr; // chain statistics scratch (mhlik_stats.hpp)
   size_t stats_cap = 0;

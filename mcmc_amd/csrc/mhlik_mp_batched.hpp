@@ -28,8 +28,10 @@
 //                    keeps chain k's running bright sum and bright count over
 //                    a fixed subset of the blocks, so there are no atomics and
 //                    the result does not depend on scheduling.
-//   mpb_final_kernel one workgroup per chain adds the tile partials of the dark
-//                    pass and the 4096 per-wave bright sums / counts.
+//   mpb_final_kernel one workgroup per (chain, local segment) adds the segment's
+//                    tile partials of the dark pass and its per-wave bright sums /
+//                    counts; with several segments or GPUs mpb_combine_kernel adds
+//                    the segments' values in order (after the in-stream all-reduce).
 //
 // Dark rows use fast float math (they are a float sum in the reference too);
 // everything that decides z or enters log(L - B) is the exact per-row
@@ -60,6 +62,16 @@ struct MpbParams {
   uint64_t u_call;
   double eps;
   int64_t n_rows;
+  int64_t row_base;     // global row of the first row this context holds (a multiple of 1024; 0 without shards)
+  int32_t seg_groups;   // workgroups of the correction kernels per local segment: kMpbFixGroups / segments
+  int32_t nseg;         // global segment count
+};
+
+// Data blocks of one local segment: [blk_lo, blk_hi) in global block numbers (blocks never straddle segments: a
+// segment is a multiple of 1024 rows; blocks beyond the last row belong to the last segment), and the segment's
+// global index.  One entry per local segment, in device memory.
+struct MpbSeg {
+  int32_t blk_lo, blk_hi, global, pad;
 };
 
 struct MpbChainArgs {
@@ -106,8 +118,8 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_kernel(const float *__rest
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
     const int row0 = wave * 256 + pass * 128;
-    const int64_t g0 = tile * kMpTileRows + row0; // global row of the pass's first row
-    if (g0 >= covered) break;                     // wave-uniform
+    const int64_t g0 = p.row_base + tile * kMpTileRows + row0; // global row of the pass's first row
+    if (g0 >= covered) break;                                  // wave-uniform
     f32x16 acc[4][NB];
     batched_f32_pass<NB, KU, 0>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
     // indicators of the two 64-row groups of this pass (a group never straddles a data block)
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__r
   for (int n = 0; n < NB; n++) sum[n] = 0.0;
 
   auto epi = [&](int64_t tile, int row0, const f32x4 (&acc)[4][NB]) {
-    const int64_t g0 = tile * kMpTileRows + row0; // global row of the pass's first row
+    const int64_t g0 = p.row_base + tile * kMpTileRows + row0; // global row of the pass's first row
     const int64_t left = covered - g0;
     if (left <= 0) return; // wave-uniform
     const int lim = left >= 64 ? 64 : (int)left;
@@ -354,8 +366,9 @@ __device__ __forceinline__ void mpb_fix_group(const float *__restrict__ Xf, cons
     const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
     if (first >= covered) break; // wave-uniform
     const int64_t row = first + lane;
-    const float *pf = Xf + (row >> 10) * gf.tile_stride + (row & 1023);
-    const double *pd = Xd + (row >> 9) * gd.tile_stride + (row & 511);
+    const int64_t lrow = row - p.row_base; // row of this context's store
+    const float *pf = Xf + (lrow >> 10) * gf.tile_stride + (lrow & 1023);
+    const double *pd = Xd + (lrow >> 9) * gd.tile_stride + (lrow & 511);
     float af[G];
     double ad[G];
 #pragma unroll
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__re
                                                                const double *__restrict__ Theta,
                                                                const float *__restrict__ Thetaf, int d_pad,
                                                                MpbParams p, const MpbChainArgs *__restrict__ ca,
+                                                               const MpbSeg *__restrict__ segtab,
                                                                int8_t *__restrict__ z, double *__restrict__ acc_out,
                                                                int32_t *__restrict__ cnt_out)
 {
@@ -472,9 +486,12 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__re
   double acc_b = 0.0;
   int32_t cnt = 0;
 
-  const int64_t chunk = ((int64_t)p.blocks + kMpbFixGroups - 1) / kMpbFixGroups;
-  const int64_t wg_begin = blockIdx.x * chunk;
-  const int64_t wg_end = wg_begin + chunk < p.blocks ? wg_begin + chunk : p.blocks;
+  // workgroup (local segment, group): the segment's blocks in seg_groups contiguous runs -- a shape that depends on
+  // the segment alone, so the sums are the same however the segments are dealt to GPUs
+  const MpbSeg sg = segtab[blockIdx.x / p.seg_groups];
+  const int64_t chunk = ((int64_t)(sg.blk_hi - sg.blk_lo) + p.seg_groups - 1) / p.seg_groups;
+  const int64_t wg_begin = sg.blk_lo + (int64_t)(blockIdx.x % p.seg_groups) * chunk;
+  const int64_t wg_end = wg_begin + chunk < sg.blk_hi ? wg_begin + chunk : sg.blk_hi;
   for (int64_t b0 = wg_begin; b0 < wg_end; b0 += NW) { // workgroup-uniform trip count
     // ---- 1. votes -------------------------------------------------------------
     const int64_t b = b0 + wave;
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
                                                                      const double *__restrict__ Theta,
                                                                      const float *__restrict__ Thetaf, int d_pad,
                                                                      MpbParams p, const MpbChainArgs *__restrict__ ca,
+                                                                     const MpbSeg *__restrict__ segtab,
                                                                      int8_t *__restrict__ z, double *__restrict__ acc_out,
                                                                      int32_t *__restrict__ cnt_out)
 {
@@ -621,9 +639,10 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
   int32_t cnt = 0;
 
   const int segs = p.block_rows >> 6;
-  const int64_t chunk = ((int64_t)p.blocks + kMpbFixGroups - 1) / kMpbFixGroups;
-  const int64_t wg_begin = blockIdx.x * chunk;
-  const int64_t wg_end = wg_begin + chunk < p.blocks ? wg_begin + chunk : p.blocks;
+  const MpbSeg sg = segtab[blockIdx.x / p.seg_groups]; // as in mpb_fix_kernel
+  const int64_t chunk = ((int64_t)(sg.blk_hi - sg.blk_lo) + p.seg_groups - 1) / p.seg_groups;
+  const int64_t wg_begin = sg.blk_lo + (int64_t)(blockIdx.x % p.seg_groups) * chunk;
+  const int64_t wg_end = wg_begin + chunk < sg.blk_hi ? wg_begin + chunk : sg.blk_hi;
 
   // Blocks worth a visit, in index order: on the shared phase, or bright for some chain (a bright block without
   // rows is visited only to be counted).  With 1/F of the blocks on the phase most are not, so the run is
@@ -669,8 +688,9 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
         for (int seg = 0; seg < segs; seg++) {
           const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
           if (first >= covered) break; // wave-uniform
-          const float *pf = Xf + (first >> 10) * gf.tile_stride + (first & 1023) + arow_f;
-          const double *pd = Xd + (first >> 9) * gd.tile_stride + (first & 511) + arow_d;
+          const int64_t lfirst = first - p.row_base; // row of this context's store
+          const float *pf = Xf + (lfirst >> 10) * gf.tile_stride + (lfirst & 1023) + arow_f;
+          const double *pd = Xd + (lfirst >> 9) * gd.tile_stride + (lfirst & 511) + arow_d;
           f32x4 af[4];
           f64x4 ad[4];
 #pragma unroll
@@ -753,19 +773,26 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
   cnt_out[(int64_t)wave_global * kBatchCols + lane] = mine ? cnt : 0;
 }
 
-// grid = K.  res[k*4 + 0] = sum over blocks bright at entry (double)
-//            res[k*4 + 1] = sum over rows of blocks dark at entry, rounded to float
-//            res[k*4 + 2] = bright blocks after resampling, res[k*4 + 3] = dark blocks
+// grid = (K, local segments).  Per chain k and local segment: the dark pass's tile partials of the segment's tiles and
+// the correction kernels' per-wave sums / counts of the segment's seg_groups * 16 waves, each in a fixed order:
+//   v0 = sum over blocks bright at entry (double), v1 = sum over rows of blocks dark at entry, rounded to float,
+//   v2 = bright blocks after resampling.
+// One segment, one GPU (slots == nullptr): res[k*4 + 0..3] = v0, v1, v2, blocks - v2 -- the whole result.
+// Otherwise slots[(k*4 + i)*nseg + global segment] = v_i, combined over segments (and GPUs) by mpb_combine_kernel.
 __global__ __launch_bounds__(kBlock) void mpb_final_kernel(const double *__restrict__ partials, int64_t pstride,
-                                                           int64_t tiles, const double *__restrict__ acc,
+                                                           const SegDesc *__restrict__ segs,
+                                                           const MpbSeg *__restrict__ segtab, int seg_groups, int nseg,
+                                                           const double *__restrict__ acc,
                                                            const int32_t *__restrict__ cnt, int32_t blocks,
-                                                           double *__restrict__ res)
+                                                           double *__restrict__ res, double *__restrict__ slots)
 {
   __shared__ double lds[kBlock / kWave];
-  const int k = blockIdx.x;
-  double dark = strided_sum<kBlock>(partials + (int64_t)k * pstride, threadIdx.x, tiles);
+  const int k = blockIdx.x, ls = blockIdx.y;
+  const SegDesc sd = segs[ls];
+  double dark = strided_sum<kBlock>(partials + (int64_t)k * pstride + sd.tile_begin, threadIdx.x, sd.tile_count);
   double br = 0.0, nb = 0.0;
-  for (int w = threadIdx.x; w < kMpbFixWaves; w += kBlock) {
+  const int w0 = ls * seg_groups * (kMpbFixBlock / kWave), w1 = w0 + seg_groups * (kMpbFixBlock / kWave);
+  for (int w = w0 + threadIdx.x; w < w1; w += kBlock) {
     br += acc[(int64_t)w * kBatchCols + k];
     nb += (double)cnt[(int64_t)w * kBatchCols + k];
   }
@@ -775,11 +802,38 @@ __global__ __launch_bounds__(kBlock) void mpb_final_kernel(const double *__restr
   __syncthreads();
   nb = block_sum(nb, lds);
   if (threadIdx.x == 0) {
-    res[k * 4 + 0] = br;
-    res[k * 4 + 1] = (double)(float)dark;
-    res[k * 4 + 2] = nb;
-    res[k * 4 + 3] = (double)blocks - nb;
+    if (slots == nullptr) {
+      res[k * 4 + 0] = br;
+      res[k * 4 + 1] = (double)(float)dark;
+      res[k * 4 + 2] = nb;
+      res[k * 4 + 3] = (double)blocks - nb;
+    } else {
+      const int g = segtab[ls].global;
+      slots[(int64_t)(k * 4 + 0) * nseg + g] = br;
+      slots[(int64_t)(k * 4 + 1) * nseg + g] = (double)(float)dark;
+      slots[(int64_t)(k * 4 + 2) * nseg + g] = nb;
+      slots[(int64_t)(k * 4 + 3) * nseg + g] = 0.0;
+    }
   }
+}
+
+// thread k: the segments' values of chain k added in segment order; the float sums are added in double and rounded to
+// float once (the single-chain path does the same on the host, mhlik_mp_loglik).
+__global__ __launch_bounds__(kWave) void mpb_combine_kernel(const double *__restrict__ slots, int nseg, int K,
+                                                            int32_t blocks, double *__restrict__ res)
+{
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  double br = 0.0, dk = 0.0, nb = 0.0;
+  for (int g = 0; g < nseg; g++) {
+    br += slots[(int64_t)(k * 4 + 0) * nseg + g];
+    dk += slots[(int64_t)(k * 4 + 1) * nseg + g];
+    nb += slots[(int64_t)(k * 4 + 2) * nseg + g];
+  }
+  res[k * 4 + 0] = br;
+  res[k * 4 + 1] = (double)(float)dk;
+  res[k * 4 + 2] = nb;
+  res[k * 4 + 3] = (double)blocks - nb;
 }
 
 } // namespace mhlik

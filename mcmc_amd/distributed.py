@@ -121,5 +121,28 @@ class ShardedLikelihood:
             bright += float(slots[2 * S + g])
         return red_d + float(np.float32(red_f)), int(bright), int(blocks) - int(bright)
 
+    def mp_reset_batched(self, block_rows, blocks, K):
+        self.local.mp_reset_batched(block_rows, blocks, K)
+
+    def mp_loglik_batched(self, Theta, resamp_factor, resamp_choose, u_seed, u_call, bound_eps):
+        """(values[K], bright[K], dark[K]) of K chains over all shards (mhlik_mp_loglik_batched's own combination:
+        per chain the segments' sums in segment order, the float sums rounded to float once)."""
+        v, nb, nd = self.local.mp_loglik_batched(Theta, resamp_factor, resamp_choose, u_seed, u_call, bound_eps)
+        if self.transport in ("rccl", "none"):
+            return v, nb, nd
+        slots = self._reduce_slots(self.local.mp_last_slots_batched().ravel()).reshape(len(v), 4, self.segments)
+        blocks = self.local._mpb[1]
+        out = np.empty(len(v))
+        bright = np.empty(len(v), dtype=np.int32)
+        for k in range(len(v)):
+            red_d = red_f = b = 0.0
+            for g in range(self.segments):
+                red_d += float(slots[k, 0, g])
+                red_f += float(slots[k, 1, g])
+                b += float(slots[k, 2, g])
+            out[k] = red_d + float(np.float32(red_f))
+            bright[k] = int(b)
+        return out, bright, (blocks - bright).astype(np.int32)
+
     def close(self):
         self.local.close()

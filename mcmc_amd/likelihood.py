@@ -213,6 +213,13 @@ class Likelihood:
         self._chk(self._lib.mhlik_mp_loglik_batched(self._ctx, C.byref(st), _ptr(Th), _ptr(out), _ptr(nb), _ptr(nd)))
         return out, nb, nd
 
+    def mp_last_slots_batched(self):
+        """[K, 4, segments] per-segment values of the last K-chain mixed-precision evaluation (sharded contexts)."""
+        _, _, K = self._mpb
+        out = np.zeros((K, 4, self.segments))
+        self._chk(self._lib.mhlik_mp_last_slots_batched(self._ctx, K, _ptr(out)))
+        return out
+
     def mp_indicators_batched(self):
         block_rows, blocks, K = self._mpb
         z = np.empty((K, blocks), dtype=np.int8)

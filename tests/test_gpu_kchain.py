@@ -124,16 +124,22 @@ def test_kchain_rejects_bad_arguments():
 
 
 @pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("f32_mode", ["exact", "split"])
-def test_mp_device_loop_equals_host_loop(shared, f32_mode):
+@pytest.mark.parametrize("f32_mode,segments,force", [("exact", 1, False), ("split", 1, False), ("split", 8, False),
+                                                     ("exact", 8, True)])
+def test_mp_device_loop_equals_host_loop(shared, f32_mode, segments, force, monkeypatch):
     """The mixed-precision K-chain sampler (mcmc_mp.cu:368-473 per chain) with the loop on the device against the
-    per-iteration host loop: same chains, same indicators at the end."""
+    per-iteration host loop: same chains, same indicators at the end -- on one segment, on eight block-aligned
+    segments (the per-segment slot path) and over a forced one-rank RCCL communicator (the path N ranks take)."""
     from mcmc_amd import Likelihood, samplers as S
 
     N, d, K, Ns, burnin = 16384, 6, 20, 90, 25
     seeds = list(range(50, 50 + K))
     th0 = np.full(d, 0.05)
-    with Likelihood(N, d, precision=3, segments=1) as lk:
+    if force:
+        monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    with Likelihood(N, d, precision=3, segments=segments, segment_align=1024 if segments > 1 else 0) as lk:
+        if force:
+            lk.comm_init(Likelihood.make_comm_id())
         lk.fill_synthetic(7)
         lk.set_batched_f32_mode(f32_mode)
         lk._mpb = (64, N // 64, K)  # geometry the C sampler resets the context to (for mp_indicators_batched)

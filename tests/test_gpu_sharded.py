@@ -189,3 +189,85 @@ def test_mixed_precision_needs_aligned_segments_and_rccl_path_with_one_rank(monk
         assert [lk.mp_loglik(t, MP_BLOCK, MP_BLOCKS, MP_RF, i % MP_RF, 1234, i, MP_EPS)
                 for i, t in enumerate(_mp_thetas())] == plain
         assert lk.mp_bound(th) == plain_bound
+
+
+# ---- K-chain mixed precision over row shards ------------------------------------------------------------------------
+KMP_K = 21
+
+
+def _kmp_inputs():
+    rng = np.random.default_rng(12)
+    thetas = rng.normal(0, 0.4, (5, KMP_K, MP_D))
+    phases = rng.integers(0, MP_RF, (5, KMP_K))
+    phases[3:] = phases[3:, :1]  # the last two calls on one phase for all chains: the dense correction kernel
+    seeds = (500 + np.arange(KMP_K)).astype(np.uint64)
+    return thetas, phases, seeds
+
+
+def _kmp_run(obj):
+    thetas, phases, seeds = _kmp_inputs()
+    obj.mp_reset_batched(MP_BLOCK, MP_BLOCKS, KMP_K)
+    out = []
+    for call in range(len(thetas)):
+        v, nb, nd = obj.mp_loglik_batched(thetas[call], MP_RF, phases[call], seeds, call, MP_EPS)
+        out.append((v.tolist(), nb.tolist(), nd.tolist()))
+    return out
+
+
+def _kmp_worker(rank, world, port, q, f32_mode):
+    import torch.distributed as dist
+
+    from mcmc_amd.distributed import ShardedLikelihood
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sl = ShardedLikelihood(MP_N, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
+    sl.local.fill_synthetic(SEED)
+    sl.local.set_batched_f32_mode(f32_mode)
+    q.put((rank, _kmp_run(sl)))
+    dist.barrier()
+    sl.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,f32_mode", [(2, "split"), (4, "exact")])
+def test_sharded_kchain_mixed_precision_equals_single_context_bitwise(world, f32_mode, monkeypatch):
+    """mhlik_mp_loglik_batched over row shards: every rank corrects and resamples the data blocks of its own rows
+    (per-chain phases and one shared phase, i.e. both correction kernels), the K x 4 x segments slots are summed over
+    the ranks, and values, bright and dark counts of a call sequence equal the single-context run with the same
+    eight segments bit for bit -- which in turn matches the one-segment path of tests/test_gpu_mp_batched.py in its
+    indicators exactly and in its values to float-sum tolerance, and runs unchanged over a forced one-rank RCCL
+    communicator (in-stream all-reduce + mpb_combine_kernel)."""
+    from mcmc_amd import Likelihood
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kmp_worker, args=(r, world, port, q, f32_mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for g in got[1:]:
+        assert g[1] == got[0][1]
+
+    def single(segments, align, force=False):
+        with Likelihood(MP_N, MP_D, precision=3, device=0, segments=segments, segment_align=align) as lk:
+            lk.fill_synthetic(SEED)
+            lk.set_batched_f32_mode(f32_mode)
+            if force:
+                lk.comm_init(Likelihood.make_comm_id())
+            return _kmp_run(lk)
+
+    eight = single(8, 1024)
+    assert eight == got[0][1]
+    one = single(1, 0)
+    for (v8, b8, d8), (v1, b1, d1) in zip(eight, one):
+        assert b8 == b1 and d8 == d1  # the indicators do not depend on how the sums are cut
+        assert np.allclose(v8, v1, rtol=2e-6, atol=0)
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    assert single(8, 1024, force=True) == eight
+    assert single(1, 0, force=True) == one  # one segment through the slot path: the same sums
