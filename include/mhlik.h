@@ -238,8 +238,9 @@ int mhlik_mp_last_slots(const mhlik_ctx *ctx, double *slots);
  * float dots of ALL rows and chains (the reference's cublasSgemv over the
  * whole matrix, :515) run as one X.Theta pass on the matrix cores; double
  * arithmetic touches only the (block, chain) pairs that are bright or
- * re-examined in this call.  Needs segments=1, world=1 (the K-chain pass is
- * single-GPU; the single-chain path above shards), both matrices. */
+ * re-examined in this call.  Needs both matrices and, as the single-chain
+ * path, segments=1 or config.segment_align a multiple of 1024 (row shards:
+ * see mhlik_mp_last_slots_batched below). */
 typedef struct mhlik_mp_batch {
   int32_t block_rows;           /* mp_str.dataBlockSz */
   int32_t blocks;               /* mp_str.dataBlocks */
@@ -351,7 +352,7 @@ int mhlik_chain_state_f32(mhlik_ctx *ctx, float *current, float *cposterior);
  * for i = 0..n-1 back to back with no host round trip.  State is double in
  * every mode (MHLIK_KCHAIN_F32 rounds the proposals to float for the pass, like
  * samplers/multichain.c does).  With world > 1 every rank calls with the same
- * numbers (F64 / F32 modes; mixed precision is single-GPU). */
+ * numbers (all three modes). */
 enum { MHLIK_KCHAIN_F64 = 1, MHLIK_KCHAIN_F32 = 2, MHLIK_KCHAIN_MP = 3 };
 
 typedef struct mhlik_kchain_mp {

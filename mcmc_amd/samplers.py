@@ -353,7 +353,7 @@ def multichain_sampler(lik, seeds, Ns, burnin, rwsd, use_f32=False):
 def mp_multichain_sampler(lik, seeds, Ns, burnin, rwsd, block_rows, blocks, resamp_factor, bound, shared_phase=False,
                           theta0=None):
     """K lock-step mixed-precision chains on an existing Likelihood context
-    (both matrices, segments=1); chain k is mp_sampler with generator seeds[k]."""
+    (both matrices; segments=1 or segment_align=1024); chain k is mp_sampler with generator seeds[k]."""
     S = load_samplers()
     K, d = len(seeds), lik.n_cols
     rngs = [Rng(s) for s in seeds]
