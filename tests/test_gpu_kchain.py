@@ -189,3 +189,32 @@ def test_kchain_over_forced_rccl_is_bitwise_equal(monkeypatch, mode, dtype):
         assert np.array_equal(plain[k], forced[k]), k
     assert np.array_equal(st0, st1) and np.array_equal(ce0, ce1)
     assert 0 < plain["accepted"].sum() < n * K
+
+
+@pytest.mark.parametrize("use_f32", [False, True])
+def test_multichain_sampler_over_forced_rccl(monkeypatch, use_f32):
+    """The C K-chain sampler on a context with a (one-rank) RCCL communicator -- what every rank of a sharded job
+    runs -- walks the chains of the plain single-GPU run, device loop and host loop alike."""
+    from mcmc_amd import Likelihood, samplers as S
+
+    N, d, K, Ns, burnin = 40_000, 9, 11, 120, 30
+    seeds = list(range(20, 20 + K))
+    rwsd = 2.38 / np.sqrt(d) * 0.03
+
+    def run(force, host):
+        with Likelihood(N, d, precision=2 if use_f32 else 1, device=0) as lk:
+            lk.fill_synthetic(4)
+            if force:
+                lk.comm_init(Likelihood.make_comm_id())
+            if host:
+                with _host_loop():
+                    return S.multichain_sampler(lk, seeds, Ns, burnin, rwsd, use_f32=use_f32)
+            return S.multichain_sampler(lk, seeds, Ns, burnin, rwsd, use_f32=use_f32)
+
+    plain = run(False, False)
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    for host in (False, True):
+        got = run(True, host)
+        assert np.array_equal(plain["samples"], got["samples"])
+        assert np.array_equal(plain["burn"], got["burn"])
+        assert np.array_equal(plain["accepted"], got["accepted"])
