@@ -85,12 +85,29 @@ def main_batched(a):
     import numpy as np
     import torch
 
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or a.gpus != 1:
-        raise SystemExit("--workload %s runs on one GPU" % a.workload)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)  # before anything touches the GPU; does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
     from mcmc_amd import Likelihood
     from mcmc_amd import samplers as S
+
+    # Several GPUs: the rows are sharded, every rank runs the same K chains (same seeds) and the K x segments slots of
+    # a pass are all-reduced in the stream by the library's own RCCL communicator; torch.distributed (gloo) only ships
+    # the communicator id and takes the maximum of the rank times.  There is no fallback for these workloads.
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        ndev = torch.cuda.device_count()
+        local_rank = int(os.environ.get("MHLIK_BENCH_DEVICE", local_rank)) % ndev
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(os.environ.get("MHLIK_BENCH_BACKEND", "gloo"))
 
     N = a.rows
     d = a.cols if a.cols != 64 else 128  # the configuration's d unless --cols says otherwise
@@ -98,8 +115,33 @@ def main_batched(a):
     rwsd = 2.38 / np.sqrt(d) * 2e-3
     seeds = list(range(a.seed, a.seed + K))
     prec = {"batched_f32": 2, "batched_f64": 1, "mp_batched": 3}[a.workload]
-    with Likelihood(N, d, precision=prec, segments=1 if a.workload == "mp_batched" else 0, timing=True) as lk:
+    # mixed precision: one segment on one GPU (no slot pass); sharded, the fixed segments must hold whole 1024-row tiles
+    mp_sharded = a.workload == "mp_batched" and world > 1
+    with Likelihood(N, d, precision=prec, segments=1 if a.workload == "mp_batched" and world == 1 else 0, timing=True,
+                    device=local_rank, rank=rank, world=world, segment_align=1024 if mp_sharded else 0) as lk:
         lk.fill_synthetic(a.data_seed)
+        if world > 1:
+            failed, why = 0, ""
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(Likelihood.make_comm_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                lk.comm_init(bytes(idt.numpy().tobytes()))
+                if lk.comm_ranks() != world:
+                    raise RuntimeError("communicator has %d ranks, expected %d" % (lk.comm_ranks(), world))
+            except Exception as e:  # noqa: BLE001 -- reported on every rank
+                why = str(e)
+                print("rank %d: in-library RCCL set-up failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                failed = 1
+            t = torch.tensor([failed], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()) != 0:
+                lk.comm_destroy()
+                dist.barrier()
+                dist.destroy_process_group()
+                raise SystemExit("bench.py: rank %d: the in-library RCCL communicator could not be built on every rank "
+                                 "(%s); no number is reported." % (rank, why or "another rank failed"))
         if a.workload == "batched_f32":
             lk.set_batched_f32_mode(a.f32_mode)
 
@@ -109,15 +151,32 @@ def main_batched(a):
                                                shared_phase=True, theta0=np.zeros(d))
             return S.multichain_sampler(lk, seeds, n, burn, rwsd, use_f32=a.workload == "batched_f32")
 
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
         run(W, 2)  # warm-up (mp: the all-bright first evaluations happen here)
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         out = run(steps, 2)  # chain start + one burn-in iteration + `steps` sampling iterations
-        torch.cuda.synchronize()
+        barrier()
         elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         evals = steps + 2
         kernel_ms, _ = lk.last_kernel()  # device time of the last step's likelihood kernels (HIP events)
-    flops = 2.0 * N * d * K
+        rccl_ranks = lk.comm_ranks()
+        local_rows = lk.info()["local_rows"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    shard = local_rows / N if N else 1.0  # this rank's share of the rows: the kernel's bytes and flops per launch
+    flops = 2.0 * N * d * K * shard
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[a.workload]
     roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -129,7 +188,7 @@ def main_batched(a):
         # the float pass runs on the bf16 pipe (three-piece split) at 3/8 of the f32 MFMA cost, so the evaluation is
         # priced against HBM: the float matrix once, plus the double rows of the re-examined phase (1/F of the blocks
         # with one shared phase; the few bright blocks are not counted)
-        nbytes = N * d * 4 + N * d * 8 / a.resamp_factor
+        nbytes = (N * d * 4 + N * d * 8 / a.resamp_factor) * shard
         gbps = nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                 "traffic": None, "kernel_ms": kernel_ms,
@@ -139,19 +198,23 @@ def main_batched(a):
     if a.workload == "batched_f32" and a.f32_mode == "split":
         # six bf16 MFMAs per float product cost 3/8 of one f32 MFMA: the pass is no longer bound by the matrix pipe
         # but by the matrix read, so it is priced against HBM (the f32-equivalent rate is reported beside it)
-        gbps = N * d * 4 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        gbps = N * d * 4 * shard / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                 "traffic": None, "kernel_ms": kernel_ms, "kernel": "lik_batched_x3_kernel",
-                "algorithmic_bytes_per_launch": N * d * 4, "f32_equivalent_TFLOPs": achieved,
+                "algorithmic_bytes_per_launch": N * d * 4 * shard, "f32_equivalent_TFLOPs": achieved,
                 "bf16_mfma_TFLOPs": 6 * achieved, "bf16_mfma_frac_of_dense_peak": 6 * achieved / 2500.0}
     line = {
-        "metric": "chain_iterations_per_sec", "value": K * evals / elapsed, "unit": "chain-it/s", "n_gpus": 1,
+        "metric": "chain_iterations_per_sec", "value": K * evals / elapsed, "unit": "chain-it/s", "n_gpus": world,
         "steps": steps, "warmup": W, "ms_per_step": elapsed / evals * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": {"batched_f32": "f32", "batched_f64": "f64", "mp_batched": "f32+f64"}[a.workload],
         "data": "synthetic",
         "config": {"workload": "%d lock-step MH chains, N=%d d=%d, %s (BASELINE configs[4])" % (K, N, d, a.workload),
                    "rows": N, "cols": d, "chains": K, "f32_mode": a.f32_mode if a.workload == "batched_f32" else None,
-                   "resamp_factor": a.resamp_factor if a.workload == "mp_batched" else None},
+                   "resamp_factor": a.resamp_factor if a.workload == "mp_batched" else None,
+                   "rows_per_gpu": local_rows,
+                   "parallelism": "rows sharded over %d GPU(s), in-stream RCCL all-reduce of the K x segments slots" % world
+                   if world > 1 else "single GPU"},
+        "rccl_ranks": rccl_ranks,
         "roofline": roof,
         "acceptance": float(np.mean(out["accepted"])) / steps,
     }

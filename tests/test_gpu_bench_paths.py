@@ -99,3 +99,21 @@ def test_bench_gpus_2_launches_itself_and_fails_loudly_without_rccl():
     # and the same self-launched command with the explicit flag does report, labelled as the fallback
     j = _bench_line(cmd + ["--allow-fallback"], dict(os.environ))
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 0 and "fallback host loop" in j["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("workload", ["batched_f64", "mp_batched"])
+def test_kchain_workloads_line_and_two_rank_refusal(workload):
+    """bench.py's K-chain workloads: one JSON line with the contract fields on one GPU; with --gpus 2 on a one-GPU box
+    the sharded set-up goes as far as RCCL's refusal of two ranks on one device and ends non-zero without a number
+    (these workloads have no torch.distributed fallback)."""
+    import subprocess
+
+    env = dict(os.environ)
+    base = [sys.executable, "bench.py", "--workload", workload, "--rows", "300000", "--cols", "16", "--chains", "20"]
+    j = _bench_line(base + ["--steps", "30"], env)
+    assert j["n_gpus"] == 1 and j["metric"] == "chain_iterations_per_sec" and j["value"] > 0
+    assert j["roofline"]["kernel_ms"] > 0 and j["config"]["parallelism"] == "single GPU"
+    out = subprocess.run(base + ["--steps", "10", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "could not be built on every rank" in out.stderr
