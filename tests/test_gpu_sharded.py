@@ -271,3 +271,34 @@ def test_sharded_kchain_mixed_precision_equals_single_context_bitwise(world, f32
     monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
     assert single(8, 1024, force=True) == eight
     assert single(1, 0, force=True) == one  # one segment through the slot path: the same sums
+
+
+@pytest.mark.parametrize("N", [5000, 1024, 700])
+def test_kchain_mixed_precision_with_empty_trailing_segments(N):
+    """Eight block-aligned segments over so few rows that the trailing segments (and, at world > 1, whole ranks) hold
+    none: blocks beyond the data are counted once (they stay bright), and the indicator counts equal the one-segment
+    run's call by call."""
+    from mcmc_amd import Likelihood
+
+    d, K, block_rows, F = 5, 7, 64, 3
+    blocks = (N + block_rows - 1) // block_rows + 2
+    rng = np.random.default_rng(N)
+    thetas = rng.normal(0, 0.4, (4, K, d))
+    phases = rng.integers(0, F, (4, K))
+    seeds = (900 + np.arange(K)).astype(np.uint64)
+
+    def run(segments, align):
+        with Likelihood(N, d, precision=3, device=0, segments=segments, segment_align=align) as lk:
+            lk.fill_synthetic(SEED)
+            lk.mp_reset_batched(block_rows, blocks, K)
+            out = []
+            for c in range(4):
+                v, nb, nd = lk.mp_loglik_batched(thetas[c], F, phases[c], seeds, c, MP_EPS)
+                out.append((v, nb.copy(), nd.copy()))
+            return out
+
+    one, eight = run(1, 0), run(8, 1024)
+    for (v1, b1, d1), (v8, b8, d8) in zip(one, eight):
+        assert np.array_equal(b1, b8) and np.array_equal(d1, d8)
+        assert np.all(b8 >= 2) and np.all(b8 + d8 == blocks)
+        assert np.allclose(v1, v8, rtol=2e-6, atol=1e-9)
