@@ -291,9 +291,13 @@ def test_kchain_mixed_precision_with_empty_trailing_segments(N):
         with Likelihood(N, d, precision=3, device=0, segments=segments, segment_align=align) as lk:
             lk.fill_synthetic(SEED)
             lk.mp_reset_batched(block_rows, blocks, K)
+            lk.mp_reset(block_rows, blocks)
             out = []
             for c in range(4):
                 v, nb, nd = lk.mp_loglik_batched(thetas[c], F, phases[c], seeds, c, MP_EPS)
+                # chain 0 again through the single-chain entry point (its own indicators, same sequence)
+                v0, nb0, nd0 = lk.mp_loglik(thetas[c, 0], block_rows, blocks, F, int(phases[c, 0]), int(seeds[0]), c, MP_EPS)
+                assert (nb0, nd0) == (nb[0], nd[0]) and abs(v0 - v[0]) <= 2e-5 * abs(v0) + 1e-9
                 out.append((v, nb.copy(), nd.copy()))
             return out
 
