@@ -325,13 +325,30 @@ typedef struct mhlik_chain_batch_f32 {
  * (start of burn_in_metropolis_gpu, mcmc_gpu.cu:141-147). */
 int mhlik_chain_begin_f64(mhlik_ctx *ctx, const double *theta0, double prior_sd, double *cposterior);
 int mhlik_chain_begin_f32(mhlik_ctx *ctx, const float *theta0, double prior_sd, float *cposterior);
-/* Continue from a state the caller holds (no likelihood pass). */
+/* Continue from a state the caller holds (no likelihood pass, and no device
+ * operation: the state is uploaded with the next batch).  begin and resume
+ * also make sure that the buffers of a following run of up to 256 iterations
+ * exist, so that such a run allocates nothing; buffers never shrink. */
 int mhlik_chain_resume_f64(mhlik_ctx *ctx, const double *current, double cposterior, double prior_sd);
 int mhlik_chain_resume_f32(mhlik_ctx *ctx, const float *current, float cposterior, double prior_sd);
 /* Run batch->n iterations from the device-side state; blocks until the
  * outputs are on the host. */
 int mhlik_chain_run_f64(mhlik_ctx *ctx, mhlik_chain_batch_f64 *batch);
 int mhlik_chain_run_f32(mhlik_ctx *ctx, mhlik_chain_batch_f32 *batch);
+/* The same in two halves, so that the caller can draw the next batch's random
+ * numbers and file the previous batch's rows while the device runs (no
+ * counterpart in the reference, whose loop is synchronous).  _submit copies
+ * increments and log_u (1 <= n <= MHLIK_CHAIN_MAX_SUBMIT; both arrays may be
+ * reused on return), queues the batch behind whatever the context's stream
+ * holds and returns; at most two batches may be in flight.  _collect waits for
+ * the OLDEST batch in flight and fills that batch's outputs: pass the same n;
+ * samples may only be asked for if the submitted batch had a samples pointer.
+ * mhlik_chain_begin / _resume / _run / _state refuse while a batch is in flight. */
+#define MHLIK_CHAIN_MAX_SUBMIT 4096
+int mhlik_chain_submit_f64(mhlik_ctx *ctx, const mhlik_chain_batch_f64 *batch);
+int mhlik_chain_submit_f32(mhlik_ctx *ctx, const mhlik_chain_batch_f32 *batch);
+int mhlik_chain_collect_f64(mhlik_ctx *ctx, mhlik_chain_batch_f64 *batch);
+int mhlik_chain_collect_f32(mhlik_ctx *ctx, mhlik_chain_batch_f32 *batch);
 /* Read the device-side state back. */
 int mhlik_chain_state_f64(mhlik_ctx *ctx, double *current, double *cposterior);
 int mhlik_chain_state_f32(mhlik_ctx *ctx, float *current, float *cposterior);

@@ -150,6 +150,10 @@ _SIGS = [
     ("mhlik_chain_resume_f32", C.c_int, [_P, _P, C.c_float, C.c_double]),
     ("mhlik_chain_run_f64", C.c_int, [_P, C.POINTER(ChainBatchF64)]),
     ("mhlik_chain_run_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
+    ("mhlik_chain_submit_f64", C.c_int, [_P, C.POINTER(ChainBatchF64)]),
+    ("mhlik_chain_submit_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
+    ("mhlik_chain_collect_f64", C.c_int, [_P, C.POINTER(ChainBatchF64)]),
+    ("mhlik_chain_collect_f32", C.c_int, [_P, C.POINTER(ChainBatchF32)]),
     ("mhlik_chain_state_f64", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("mhlik_chain_state_f32", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     ("mhlik_host_alloc", C.c_int, [C.c_size_t, C.POINTER(_P)]),

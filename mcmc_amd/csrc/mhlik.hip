@@ -134,19 +134,33 @@ struct Store {
   size_t bytes = 0;
 };
 
-// Device-resident MH chain (mhlik_chain.hpp): state + one batch of buffers.
+// Device-resident MH chain (mhlik_chain.hpp): the state, and two batch slots so that a second batch can be
+// submitted while the first one runs (mhlik_chain_submit / _collect).  A slot owns one upload image and one download
+// image on the device and their page-locked host mirrors; everything is allocated by begin / resume (for at least
+// kChainMinCap iterations) and only ever grows, so a run that follows a burn-in allocates nothing.
+struct ChainSlot {
+  unsigned char *dev_up = nullptr, *dev_down = nullptr; // device images
+  unsigned char *h_up = nullptr, *h_down = nullptr;     // page-locked host mirrors
+  int64_t cap_n = 0;                                    // iterations the images hold (8-byte elements)
+  hipEvent_t done = nullptr;                            // recorded after the batch's download
+  std::vector<hipEvent_t> ev;                           // timing pairs, created with the slot
+  int64_t n = 0;                                        // the batch in flight
+  int pairs = 0;
+  bool want_samples = false;
+};
 struct ChainHost {
   ChainHdr *hdr = nullptr;
   void *cur = nullptr, *prop = nullptr;
   size_t state_bytes = 0;
-  void *inc = nullptr, *logu = nullptr, *samples = nullptr;
-  double *lik = nullptr, *ratio = nullptr;
-  unsigned char *acc = nullptr;
-  int64_t cap_n = 0;
-  size_t batch_elem = 0;
+  ChainSlot slot[2];
+  int head = 0, inflight = 0; // slot[head] holds the oldest batch in flight
   double pdf_norm = 0, abs_sigma = 1;
   int prec = 0;
-  std::vector<hipEvent_t> ev;
+  // mhlik_chain_resume keeps the caller's state here; the next batch carries it to the device (load_state).
+  // After a collect that leaves nothing in flight it is the device-side state again (host_state_valid).
+  bool load_state = false, host_state_valid = false;
+  ChainHdr host_hdr;
+  std::vector<unsigned char> host_cur;
 };
 
 // K lock-step chains on the device (mhlik_kchain.hpp): states + one batch of buffers.

@@ -44,6 +44,14 @@ struct ChainDev {
   int d, n;
   double pdf_norm;     // 1 / (sqrt(2 pi) |sigma|)
   double abs_sigma;
+  // A batch travels as ONE upload image and ONE download image (mhlik_chain_abi.inc): the state a caller resumes
+  // from rides at the head of the upload image and is taken over by the batch's first kernel (load_state != 0);
+  // the batch's last step kernel leaves a copy of the state at the head of the download image.
+  const ChainHdr *hdr_in;
+  const void *cur_in; // T[d]
+  ChainHdr *hdr_out;
+  void *cur_out;      // T[d]
+  int load_state;
 };
 
 // log(gsl_ran_gaussian_pdf(x, sigma)): u = x/|sigma|; p = norm * exp(-u*u/2)
@@ -59,8 +67,18 @@ __device__ __forceinline__ double log_gauss_pdf(double x, double norm, double ab
 // the step kernel)
 template <typename T> __global__ __launch_bounds__(kBlock) void chain_propose_kernel(ChainDev c, int it)
 {
-  const T *cur = (const T *)c.cur, *inc = (const T *)c.inc;
-  T *prop = (T *)c.prop;
+  const T *inc = (const T *)c.inc;
+  T *cur = (T *)c.cur, *prop = (T *)c.prop;
+  if (c.load_state) { // the state mhlik_chain_resume handed over, uploaded with this batch
+    const T *cur_in = (const T *)c.cur_in;
+    if (threadIdx.x == 0) *c.hdr = *c.hdr_in;
+    for (int k = threadIdx.x; k < c.d; k += kBlock) {
+      const T x = cur_in[k];
+      cur[k] = x;
+      prop[k] = x + inc[(int64_t)it * c.d + k];
+    }
+    return;
+  }
   for (int k = threadIdx.x; k < c.d; k += kBlock) prop[k] = cur[k] + inc[(int64_t)it * c.d + k];
 }
 
@@ -144,14 +162,17 @@ __global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int i
   const bool accept = s_accept != 0;
   const T *inc = (const T *)c.inc;
   T *samples = (T *)c.samples;
+  const bool last = mode == 0 && it + 1 == c.n && c.cur_out != nullptr;
   for (int k = threadIdx.x; k < d; k += blockDim.x) {
     const T x = accept ? prop[k] : cur[k];
     if (accept) cur[k] = x;
     if (mode == 0) {
-      samples[(int64_t)it * d + k] = x;
+      if (samples) samples[(int64_t)it * d + k] = x;
       if (it + 1 < c.n) prop[k] = x + inc[(int64_t)(it + 1) * d + k];
+      if (last) ((T *)c.cur_out)[k] = x;
     }
   }
+  if (last && threadIdx.x == 0) *c.hdr_out = *c.hdr; // thread 0 wrote the header above
 }
 
 } // namespace mhlik

@@ -80,7 +80,7 @@ static int step_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, mcmc_int_
   return accept;
 }
 
-/* n iterations of step_f with the chain kept on the device (mhlik_chain_run_f32):
+/* n iterations of step_f with the chain kept on the device (mhlik_chain_submit_f32 / _collect_f32):
  * the host draws the batch's numbers in step_f's order -- d float-rounded
  * Gaussians, then one uniform rounded to float -- and the device runs the
  * float chain: float proposal, float prior accumulator += double log(pdf),
@@ -90,9 +90,9 @@ static void chain_steps_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, m
 {
   const int d = mcin.ddata;
   if (n <= 0) return;
-  const long cap = n < 65536 ? n : 65536;
+  const long cap = n < MHLIK_CHAIN_MAX_SUBMIT ? n : MHLIK_CHAIN_MAX_SUBMIT;
   float *inc = (float *)malloc(sizeof(float) * (size_t)cap * d);
-  float *logu = (float *)malloc(sizeof(float) * (size_t)cap);
+  float *logu = (float *)malloc(sizeof(float) * (size_t)cap * 2); /* per batch in flight, for the trace */
   double *lk = (double *)malloc(sizeof(double) * (size_t)cap);
   double *ratio = (double *)malloc(sizeof(double) * (size_t)cap);
   uint8_t *acc = (uint8_t *)malloc((size_t)cap);
@@ -103,30 +103,50 @@ static void chain_steps_f(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, float sd, m
   MH_CHECK(mhlik_chain_resume_f32(lik, v.currentf, loc->cposteriorf, (double)PRIOR_SD), lik);
   double ms_sum = 0;
   long ms_n = 0;
-  for (long done = 0; done < n; done += cap) {
-    const long m = n - done < cap ? n - done : cap;
-    for (long i = 0; i < m; i++) {
-      for (int k = 0; k < d; k++) inc[i * d + k] = (float)gsl_ran_gaussian_ziggurat(r, (double)sd);
-      loc->uf = gsl_rng_uniform(r);
-      logu[i] = logf(loc->uf);
+  /* two batches in flight: the host draws batch i+1 and files batch i-1 while the device runs batch i (mh_core.c) */
+  long sub = 0, col = 0, k = 0, fly[2] = {0, 0};
+  int nfly = 0, head = 0;
+  while (col < n) {
+    while (sub < n && nfly < 2) {
+      const long m = mh_chain_batch_size(k++, n - sub);
+      const int slot = (head + nfly) % 2;
+      float *lu = logu + (size_t)slot * cap;
+      for (long i = 0; i < m; i++) {
+        for (int j = 0; j < d; j++) inc[i * d + j] = (float)gsl_ran_gaussian_ziggurat(r, (double)sd);
+        loc->uf = gsl_rng_uniform(r);
+        lu[i] = logf(loc->uf);
+      }
+      mhlik_chain_batch_f32 b;
+      memset(&b, 0, sizeof b);
+      b.n = m;
+      b.increments = inc;
+      b.log_u = lu;
+      b.samples = rows_out ? rows_out + sub * d : NULL;
+      MH_CHECK(mhlik_chain_submit_f32(lik, &b), lik);
+      fly[slot] = m;
+      nfly++;
+      sub += m;
     }
+    const long m = fly[head];
+    const float *lu = logu + (size_t)head * cap;
     mhlik_chain_batch_f32 b;
     memset(&b, 0, sizeof b);
     b.n = m;
-    b.increments = inc;
-    b.log_u = logu;
-    b.samples = rows_out ? rows_out + done * d : NULL;
+    b.samples = rows_out ? rows_out + col * d : NULL;
     b.lik = lk;
     b.ratio = ratio;
     b.accepted = acc;
-    MH_CHECK(mhlik_chain_run_f32(lik, &b), lik);
+    MH_CHECK(mhlik_chain_collect_f32(lik, &b), lik);
     if (accepted) *accepted += (int)b.n_accepted;
-    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], logu[i], acc[i]);
+    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], lu[i], acc[i]);
     loc->acceptancef = (float)ratio[m - 1];
     if (b.kernel_samples > 0) {
       ms_sum += (double)b.kernel_ms * b.kernel_samples;
       ms_n += b.kernel_samples;
     }
+    head = (head + 1) % 2;
+    nfly--;
+    col += m;
   }
   MH_CHECK(mhlik_chain_state_f32(lik, v.currentf, &loc->cposteriorf), lik);
   if (res && ms_n > 0) {

@@ -187,51 +187,79 @@ int mh_device_stats_enabled(void)
   return (e && e[0] == '1') ? 0 : 1;
 }
 
-#define MH_CHAIN_MAX_BATCH 65536
+/* Batch sizes of the submit / collect pipeline: a short first batch so that the device starts after a few dozen
+ * draws, then longer ones; two batches are in flight, so the host draws batch i+1 and files batch i-1 while the
+ * device runs batch i.  A run of up to 64 iterations is one batch. */
+long mh_chain_batch_size(long k, long left)
+{
+  static const long ramp[] = {64, 256, 1024};
+  const long m = k < 3 ? ramp[k] : MHLIK_CHAIN_MAX_SUBMIT;
+  return left < m ? left : m;
+}
 
 void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,
                       double *rows_out, int *accepted, out_str *res, int prior_sd)
 {
   const int d = mcin.ddata;
   if (n <= 0) return;
-  const long cap = n < MH_CHAIN_MAX_BATCH ? n : MH_CHAIN_MAX_BATCH;
+  const long cap = n < MHLIK_CHAIN_MAX_SUBMIT ? n : MHLIK_CHAIN_MAX_SUBMIT;
+  /* the library copies increments and log u at submit, so one set of input arrays serves every batch; log u is kept
+   * per batch in flight for the trace */
   double *inc = (double *)malloc(sizeof(double) * (size_t)cap * d);
-  double *logu = (double *)malloc(sizeof(double) * (size_t)cap);
+  double *logu = (double *)malloc(sizeof(double) * (size_t)cap * 2);
   double *lk = (double *)malloc(sizeof(double) * (size_t)cap);
   double *ratio = (double *)malloc(sizeof(double) * (size_t)cap);
   uint8_t *acc = (uint8_t *)malloc((size_t)cap);
-  double *rows = rows_out ? NULL : (double *)malloc(sizeof(double) * (size_t)cap * d);
-  if (!inc || !logu || !lk || !ratio || !acc || (!rows_out && !rows)) {
+  if (!inc || !logu || !lk || !ratio || !acc) {
     fprintf(stderr, "ERROR: chain batch vectors did not allocate.\n");
     exit(MHLIK_ENOMEM);
   }
   MH_CHECK(mhlik_chain_resume_f64(lik, v.current, loc->cposterior, (double)prior_sd), lik);
   double ms_sum = 0;
   long ms_n = 0;
-  for (long done = 0; done < n; done += cap) {
-    const long m = n - done < cap ? n - done : cap;
-    for (long i = 0; i < m; i++) {
-      for (int k = 0; k < d; k++) inc[i * d + k] = gsl_ran_gaussian_ziggurat(r, sd);
-      loc->u = gsl_rng_uniform(r);
-      logu[i] = log(loc->u);
+  long sub = 0, col = 0, k = 0, fly[2] = {0, 0};
+  int nfly = 0, head = 0;
+  while (col < n) {
+    while (sub < n && nfly < 2) {
+      const long m = mh_chain_batch_size(k++, n - sub);
+      const int slot = (head + nfly) % 2;
+      double *lu = logu + (size_t)slot * cap;
+      for (long i = 0; i < m; i++) {
+        for (int j = 0; j < d; j++) inc[i * d + j] = gsl_ran_gaussian_ziggurat(r, sd);
+        loc->u = gsl_rng_uniform(r);
+        lu[i] = log(loc->u);
+      }
+      mhlik_chain_batch_f64 b;
+      memset(&b, 0, sizeof b);
+      b.n = m;
+      b.increments = inc;
+      b.log_u = lu;
+      b.samples = rows_out ? rows_out + sub * d : NULL;
+      MH_CHECK(mhlik_chain_submit_f64(lik, &b), lik);
+      fly[slot] = m;
+      nfly++;
+      sub += m;
     }
+    const long m = fly[head];
+    const double *lu = logu + (size_t)head * cap;
     mhlik_chain_batch_f64 b;
     memset(&b, 0, sizeof b);
     b.n = m;
-    b.increments = inc;
-    b.log_u = logu;
-    b.samples = rows_out ? rows_out + done * d : rows;
+    b.samples = rows_out ? rows_out + col * d : NULL;
     b.lik = lk;
     b.ratio = ratio;
     b.accepted = acc;
-    MH_CHECK(mhlik_chain_run_f64(lik, &b), lik);
+    MH_CHECK(mhlik_chain_collect_f64(lik, &b), lik);
     if (accepted) *accepted += (int)b.n_accepted;
-    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], logu[i], acc[i]);
+    for (long i = 0; i < m; i++) mh_trace_push(lk[i], ratio[i], lu[i], acc[i]);
     loc->acceptance = ratio[m - 1];
     if (b.kernel_samples > 0) {
       ms_sum += (double)b.kernel_ms * b.kernel_samples;
       ms_n += b.kernel_samples;
     }
+    head = (head + 1) % 2;
+    nfly--;
+    col += m;
   }
   MH_CHECK(mhlik_chain_state_f64(lik, v.current, &loc->cposterior), lik);
   if (res && ms_n > 0) {
@@ -249,7 +277,6 @@ void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc
   free(lk);
   free(ratio);
   free(acc);
-  free(rows);
 }
 
 /* ---- RNG set-up: src/util/alloc_util.c:249-277 ---- */

@@ -43,11 +43,12 @@ double mh_log_prior_d(const double *sample, int d, int prior_sd);
 
 /* n iterations of mh_step_d (log(u) <= ratio rule) with the chain kept on the
  * device: the host draws the batch's random numbers in the same order, the
- * device runs the iterations back to back (mhlik_chain_run_f64).  rows_out:
+ * device runs the iterations back to back (mhlik_chain_submit_f64 / _collect_f64, two batches in flight).  rows_out:
  * n rows of d, the state after each iteration (NULL: not kept).  v.current /
  * loc->cposterior are the state on entry and on return. */
 int mh_device_chain_enabled(void);
 int mh_device_stats_enabled(void);
+long mh_chain_batch_size(long k, long left); /* size of the k-th submitted batch when `left` iterations remain */
 void mh_chain_steps_d(mhlik_ctx *lik, gsl_rng *r, mcmc_str mcin, double sd, mcmc_int_v v, mcmc_int *loc, long n,
                       double *rows_out, int *accepted, out_str *res, int prior_sd);
 

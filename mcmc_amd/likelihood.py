@@ -259,6 +259,28 @@ class Likelihood:
         return dict(samples=samples, lik=lik, ratio=ratio, accepted=acc, n_accepted=b.n_accepted,
                     kernel_ms=b.kernel_ms, kernel_samples=b.kernel_samples)
 
+    def chain_submit(self, increments, log_u, dtype=np.float64, want_samples=True):
+        """Queue len(log_u) <= 4096 iterations and return at once (at most two batches in flight)."""
+        inc = np.ascontiguousarray(increments, dtype=dtype)
+        lu = np.ascontiguousarray(log_u, dtype=dtype)
+        B = L.ChainBatchF64 if dtype == np.float64 else L.ChainBatchF32
+        b = B(n=inc.shape[0], increments=_ptr(inc).value, log_u=_ptr(lu).value,
+              samples=_ptr(inc).value if want_samples else None)  # any non-NULL pointer: "keep the rows"
+        fn = self._lib.mhlik_chain_submit_f64 if dtype == np.float64 else self._lib.mhlik_chain_submit_f32
+        self._chk(fn(self._ctx, C.byref(b)))
+
+    def chain_collect(self, n, dtype=np.float64, want_samples=True):
+        """Wait for the oldest batch in flight (n iterations) and return its outputs like chain_run."""
+        samples = np.empty((n, self.n_cols), dtype=dtype) if want_samples else None
+        lik, ratio, acc = np.empty(n), np.empty(n), np.empty(n, dtype=np.uint8)
+        B = L.ChainBatchF64 if dtype == np.float64 else L.ChainBatchF32
+        b = B(n=n, samples=_ptr(samples).value if want_samples else None, lik=_ptr(lik).value,
+              ratio=_ptr(ratio).value, accepted=_ptr(acc).value)
+        fn = self._lib.mhlik_chain_collect_f64 if dtype == np.float64 else self._lib.mhlik_chain_collect_f32
+        self._chk(fn(self._ctx, C.byref(b)))
+        return dict(samples=samples, lik=lik, ratio=ratio, accepted=acc, n_accepted=b.n_accepted,
+                    kernel_ms=b.kernel_ms, kernel_samples=b.kernel_samples)
+
     def chain_state(self, dtype=np.float64):
         cur = np.empty(self.n_cols, dtype=dtype)
         if dtype == np.float64:

@@ -146,3 +146,81 @@ def test_sp_device_chain_equals_host_loop(monkeypatch, N, d):
     assert np.array_equal(host["samples"], dev["samples"])
     assert np.array_equal(host["burn"], dev["burn"])
     assert host["acceptance"] == dev["acceptance"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chain_submit_collect_pipeline_equals_run(dtype):
+    """mhlik_chain_submit / _collect with two batches in flight (and a slot that grows while the other one is in
+    flight) give the bits of one blocking mhlik_chain_run; begin / resume / run / state refuse meanwhile."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd._lib import MhlikError
+
+    N, d = 30000, 7
+    rng = np.random.default_rng(5)
+    sizes = [64, 256, 700, 3, 4096, 1]
+    n = sum(sizes)
+    inc = rng.normal(0, 0.01, (n, d)).astype(dtype)
+    logu = np.log(rng.uniform(size=n)).astype(dtype)
+    with Likelihood(N, d, precision=3) as lk:
+        lk.fill_synthetic(77)
+        cp = lk.chain_begin(np.zeros(d, dtype=dtype), 10.0, dtype=dtype)
+        ref = lk.chain_run(inc, logu, dtype=dtype)
+        ref_state = lk.chain_state(dtype=dtype)
+
+        lk.chain_resume(np.zeros(d, dtype=dtype), cp, 10.0, dtype=dtype)
+        assert lk.chain_state(dtype=dtype)[1] == cp  # resume alone: the host-side state, no device operation
+        outs, fly, at = [], [], 0
+        for m in sizes:
+            if len(fly) == 2:
+                outs.append(lk.chain_collect(fly.pop(0), dtype=dtype))
+            lk.chain_submit(inc[at:at + m], logu[at:at + m], dtype=dtype)
+            fly.append(m)
+            at += m
+        with pytest.raises(MhlikError, match="in flight"):
+            lk.chain_submit(inc[:1], logu[:1], dtype=dtype)
+        with pytest.raises(MhlikError, match="in flight"):
+            lk.chain_state(dtype=dtype)
+        with pytest.raises(MhlikError, match="in flight"):
+            lk.chain_run(inc[:1], logu[:1], dtype=dtype)
+        with pytest.raises(MhlikError, match="oldest batch"):
+            lk.chain_collect(fly[0] + 1, dtype=dtype)
+        while fly:
+            outs.append(lk.chain_collect(fly.pop(0), dtype=dtype))
+        with pytest.raises(MhlikError, match="no chain batch in flight"):
+            lk.chain_collect(1, dtype=dtype)
+        for k in ("samples", "lik", "ratio", "accepted"):
+            assert np.array_equal(np.concatenate([o[k] for o in outs]), ref[k]), k
+        assert sum(o["n_accepted"] for o in outs) == ref["n_accepted"]
+        st = lk.chain_state(dtype=dtype)
+        assert np.array_equal(st[0], ref_state[0]) and st[1] == ref_state[1]
+        with pytest.raises(MhlikError, match="1..4096"):
+            lk.chain_submit(np.zeros((4097, d), dtype=dtype), np.zeros(4097, dtype=dtype), dtype=dtype)
+        # a batch submitted without a samples array cannot hand rows out
+        lk.chain_submit(inc[:5], logu[:5], dtype=dtype, want_samples=False)
+        with pytest.raises(MhlikError, match="without a samples array"):
+            lk.chain_collect(5, dtype=dtype)
+        o = lk.chain_collect(5, dtype=dtype, want_samples=False)
+        assert o["samples"] is None and len(o["lik"]) == 5
+
+
+def test_run_after_burn_in_allocates_nothing():
+    """The driver's shape: a 4-iteration burn-in, then 20 timed iterations.  The second call must find every buffer
+    in place: free device memory does not move, and neither does it over a longer run that fits the slots."""
+    import torch
+
+    from mcmc_amd import Likelihood
+
+    N, d = 20000, 16
+    rng = np.random.default_rng(1)
+    inc = rng.normal(0, 0.01, (256, d))
+    logu = np.log(rng.uniform(size=256))
+    with Likelihood(N, d, timing=True) as lk:
+        lk.fill_synthetic(5)
+        lk.chain_resume(np.zeros(d), -1e4, 10.0)
+        lk.chain_run(inc[:4], logu[:4])
+        free0 = torch.cuda.mem_get_info(0)[0]
+        lk.chain_resume(np.zeros(d), -1e4, 10.0)
+        a = lk.chain_run(inc[:20], logu[:20])
+        assert a["kernel_samples"] == 5  # every fourth launch of a short batch is bracketed with events (every eighth of a long one)
+        lk.chain_run(inc, logu)
+        assert torch.cuda.mem_get_info(0)[0] == free0
