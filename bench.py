@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--allow-fallback", action="store_true",
                     help="--gpus N>1: if the in-library RCCL communicator cannot be built, time the Python host loop that "
                          "all-reduces through torch.distributed instead of exiting non-zero (rehearsals on a one-GPU box)")
+    ap.add_argument("--no-kchain", action="store_true", help="skip the BASELINE configs[4] side measurements (extra.kchain)")
+    ap.add_argument("--kchain-steps", type=int, default=100, help="lock-step iterations of each extra.kchain measurement")
     ap.add_argument("--contested-iters", type=int, default=60,
                     help="MH iterations of the contested-decision parity check of the cpu_baseline leg (0 = skip)")
     return ap.parse_args()
@@ -78,46 +80,24 @@ def self_launch(a):
 MFMA_PEAK_TFLOPS = {"batched_f32": 157.3, "batched_f64": 78.6, "mp_batched": 157.3}  # dense, MI355X_MICROARCH.md
 
 
-def main_batched(a):
-    """BASELINE configs[4]: one step = one lock-step iteration of K chains (host
-    proposals, one batched likelihood pass, host accept tests), the C loop of
-    samplers/multichain.c.  Roofline: the X.Theta pass on the matrix cores."""
+def kchain_measure(a, workload, N, d, K, steps, W, rank=0, local_rank=0, world=1, dist=None, f32_mode=None,
+                   resamp_factor=None):
+    """One K-chain workload of BASELINE configs[4] through the C multichain samplers (whole lock-step iteration on the
+    device): returns the JSON line as a dict (on every rank; rank 0 prints it)."""
     import numpy as np
     import torch
 
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        self_launch(a)  # before anything touches the GPU; does not return
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
     from mcmc_amd import Likelihood
     from mcmc_amd import samplers as S
 
-    # Several GPUs: the rows are sharded, every rank runs the same K chains (same seeds) and the K x segments slots of
-    # a pass are all-reduced in the stream by the library's own RCCL communicator; torch.distributed (gloo) only ships
-    # the communicator id and takes the maximum of the rank times.  There is no fallback for these workloads.
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        ndev = torch.cuda.device_count()
-        local_rank = int(os.environ.get("MHLIK_BENCH_DEVICE", local_rank)) % ndev
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(os.environ.get("MHLIK_BENCH_BACKEND", "gloo"))
-
-    N = a.rows
-    d = a.cols if a.cols != 64 else 128  # the configuration's d unless --cols says otherwise
-    K, steps, W = a.chains, a.steps, max(a.warmup, 2)
+    f32_mode = f32_mode or a.f32_mode
+    resamp_factor = resamp_factor or a.resamp_factor
     rwsd = 2.38 / np.sqrt(d) * 2e-3
     seeds = list(range(a.seed, a.seed + K))
-    prec = {"batched_f32": 2, "batched_f64": 1, "mp_batched": 3}[a.workload]
+    prec = {"batched_f32": 2, "batched_f64": 1, "mp_batched": 3}[workload]
     # mixed precision: one segment on one GPU (no slot pass); sharded, the fixed segments must hold whole 1024-row tiles
-    mp_sharded = a.workload == "mp_batched" and world > 1
-    with Likelihood(N, d, precision=prec, segments=1 if a.workload == "mp_batched" and world == 1 else 0, timing=True,
+    mp_sharded = workload == "mp_batched" and world > 1
+    with Likelihood(N, d, precision=prec, segments=1 if workload == "mp_batched" and world == 1 else 0, timing=True,
                     device=local_rank, rank=rank, world=world, segment_align=1024 if mp_sharded else 0) as lk:
         lk.fill_synthetic(a.data_seed)
         if world > 1:
@@ -142,14 +122,15 @@ def main_batched(a):
                 dist.destroy_process_group()
                 raise SystemExit("bench.py: rank %d: the in-library RCCL communicator could not be built on every rank "
                                  "(%s); no number is reported." % (rank, why or "another rank failed"))
-        if a.workload == "batched_f32":
-            lk.set_batched_f32_mode(a.f32_mode)
+            rank_report(rank, local_rank, lk.comm_ranks())
+        if workload == "batched_f32":
+            lk.set_batched_f32_mode(f32_mode)
 
         def run(n, burn):
-            if a.workload == "mp_batched":
-                return S.mp_multichain_sampler(lk, seeds, n, burn, rwsd, 64, N // 64, a.resamp_factor, 1.7e-7,
+            if workload == "mp_batched":
+                return S.mp_multichain_sampler(lk, seeds, n, burn, rwsd, 64, N // 64, resamp_factor, 1.7e-7,
                                                shared_phase=True, theta0=np.zeros(d))
-            return S.multichain_sampler(lk, seeds, n, burn, rwsd, use_f32=a.workload == "batched_f32")
+            return S.multichain_sampler(lk, seeds, n, burn, rwsd, use_f32=workload == "batched_f32")
 
         def barrier():
             if world > 1:
@@ -170,32 +151,27 @@ def main_batched(a):
         kernel_ms, _ = lk.last_kernel()  # device time of the last step's likelihood kernels (HIP events)
         rccl_ranks = lk.comm_ranks()
         local_rows = lk.info()["local_rows"]
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank != 0:
-        return
     shard = local_rows / N if N else 1.0  # this rank's share of the rows: the kernel's bytes and flops per launch
     flops = 2.0 * N * d * K * shard
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    peak = MFMA_PEAK_TFLOPS[a.workload]
+    peak = MFMA_PEAK_TFLOPS[workload]
     roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None, "kernel_ms": kernel_ms,
             "kernel": {"batched_f32": "lik_batched_f32_kernel", "batched_f64": "lik_batched_f64_kernel",
-                       "mp_batched": "mpb_dark_kernel + mpb_fix_kernel + mpb_final_kernel (flops of the float pass)"}[a.workload],
+                       "mp_batched": "mpb_dark_kernel + mpb_fix_kernel + mpb_final_kernel (flops of the float pass)"}[workload],
             "algorithmic_flops_per_launch": flops}
-    if a.workload == "mp_batched":
+    if workload == "mp_batched":
         # the float pass runs on the bf16 pipe (three-piece split) at 3/8 of the f32 MFMA cost, so the evaluation is
         # priced against HBM: the float matrix once, plus the double rows of the re-examined phase (1/F of the blocks
         # with one shared phase; the few bright blocks are not counted)
-        nbytes = (N * d * 4 + N * d * 8 / a.resamp_factor) * shard
+        nbytes = (N * d * 4 + N * d * 8 / resamp_factor) * shard
         gbps = nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                 "traffic": None, "kernel_ms": kernel_ms,
                 "kernel": "mpb_dark_x3_kernel + mpb_fix_dense_kernel + mpb_final_kernel (one evaluation)",
                 "algorithmic_bytes_per_launch": nbytes, "f32_equivalent_TFLOPs": achieved,
                 "bf16_mfma_TFLOPs": 6 * achieved, "bf16_mfma_frac_of_dense_peak": 6 * achieved / 2500.0}
-    if a.workload == "batched_f32" and a.f32_mode == "split":
+    if workload == "batched_f32" and f32_mode == "split":
         # six bf16 MFMAs per float product cost 3/8 of one f32 MFMA: the pass is no longer bound by the matrix pipe
         # but by the matrix read, so it is priced against HBM (the f32-equivalent rate is reported beside it)
         gbps = N * d * 4 * shard / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -203,14 +179,14 @@ def main_batched(a):
                 "traffic": None, "kernel_ms": kernel_ms, "kernel": "lik_batched_x3_kernel",
                 "algorithmic_bytes_per_launch": N * d * 4 * shard, "f32_equivalent_TFLOPs": achieved,
                 "bf16_mfma_TFLOPs": 6 * achieved, "bf16_mfma_frac_of_dense_peak": 6 * achieved / 2500.0}
-    line = {
+    return {
         "metric": "chain_iterations_per_sec", "value": K * evals / elapsed, "unit": "chain-it/s", "n_gpus": world,
         "steps": steps, "warmup": W, "ms_per_step": elapsed / evals * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": {"batched_f32": "f32", "batched_f64": "f64", "mp_batched": "f32+f64"}[a.workload],
+        "vs_baseline": None, "dtype": {"batched_f32": "f32", "batched_f64": "f64", "mp_batched": "f32+f64"}[workload],
         "data": "synthetic",
-        "config": {"workload": "%d lock-step MH chains, N=%d d=%d, %s (BASELINE configs[4])" % (K, N, d, a.workload),
-                   "rows": N, "cols": d, "chains": K, "f32_mode": a.f32_mode if a.workload == "batched_f32" else None,
-                   "resamp_factor": a.resamp_factor if a.workload == "mp_batched" else None,
+        "config": {"workload": "%d lock-step MH chains, N=%d d=%d, %s (BASELINE configs[4])" % (K, N, d, workload),
+                   "rows": N, "cols": d, "chains": K, "f32_mode": f32_mode if workload == "batched_f32" else None,
+                   "resamp_factor": resamp_factor if workload == "mp_batched" else None,
                    "rows_per_gpu": local_rows,
                    "parallelism": "rows sharded over %d GPU(s), in-stream RCCL all-reduce of the K x segments slots" % world
                    if world > 1 else "single GPU"},
@@ -218,7 +194,66 @@ def main_batched(a):
         "roofline": roof,
         "acceptance": float(np.mean(out["accepted"])) / steps,
     }
-    print(json.dumps(line), flush=True)
+
+
+INIT_TIMEOUT_S = 120  # rendezvous and every control-plane collective: a rank that died must not hang the others
+
+
+def rank_report(rank, local_rank, comm_ranks):
+    """One line per rank on stderr: enough to tell, from the log of a failed multi-GPU run, which process sat on
+    which device and whether its communicator came up."""
+    import torch
+
+    try:
+        dev = torch.cuda.current_device()
+        p = torch.cuda.get_device_properties(dev)
+        bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        name = p.name
+    except Exception as e:  # noqa: BLE001 -- a diagnostic must not end the run
+        dev, bus, name = -1, "?", "(%s)" % e
+    print("bench.py: rank %d LOCAL_RANK=%s device %d pci %s %s pid %d mhlik_comm_ranks=%d" %
+          (rank, os.environ.get("LOCAL_RANK", "-"), dev, bus, name, os.getpid(), comm_ranks), file=sys.stderr, flush=True)
+
+
+def main_batched(a):
+    """BASELINE configs[4]: one step = one lock-step iteration of K chains (host
+    proposals, one batched likelihood pass, host accept tests), the C loop of
+    samplers/multichain.c.  Roofline: the X.Theta pass on the matrix cores."""
+    import datetime
+
+    import torch
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)  # before anything touches the GPU; does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
+
+    # Several GPUs: the rows are sharded, every rank runs the same K chains (same seeds) and the K x segments slots of
+    # a pass are all-reduced in the stream by the library's own RCCL communicator; torch.distributed (gloo) only ships
+    # the communicator id and takes the maximum of the rank times.  There is no fallback for these workloads.
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        ndev = torch.cuda.device_count()
+        local_rank = int(os.environ.get("MHLIK_BENCH_DEVICE", local_rank)) % ndev
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(os.environ.get("MHLIK_BENCH_BACKEND", "gloo"),
+                                timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
+
+    N = a.rows
+    d = a.cols if a.cols != 64 else 128  # the configuration's d unless --cols says otherwise
+    line = kchain_measure(a, a.workload, N, d, a.chains, a.steps, max(a.warmup, 2), rank, local_rank, world, dist)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -227,6 +262,8 @@ def main():
         return main_batched(a)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)  # before anything touches the GPU; does not return
+    import datetime
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -259,10 +296,11 @@ def main():
     from mcmc_amd import samplers as S
 
     if world > 1:
+        tmo = datetime.timedelta(seconds=INIT_TIMEOUT_S)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     def barrier():
         if world > 1:
@@ -325,6 +363,8 @@ def main():
         return el, kms, acc
 
     lk, in_library_rccl = make_context(N)
+    if world > 1:
+        rank_report(rank, local_rank, lk.comm_ranks())
     K, W = a.steps, a.warmup
     rwsd = 2.38 / np.sqrt(d) * 2e-3
     elapsed, kernel_ms, n_accepted = timed_chain(lk, in_library_rccl, N, K, W)
@@ -390,6 +430,19 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a side measurement never costs the main line
             big["error"] = str(e)
         out.setdefault("extra", {})["n100m"] = big
+    # ---- BASELINE configs[4] beside the metric (single GPU, the metric's size only): 64 lock-step chains, d=128 ----
+    if world == 1 and not a.no_extras and not a.no_kchain and (N, d) == (10_000_000, 64):
+        kc = {}
+        for name, wl, kw in (("batched_f64", "batched_f64", {}), ("batched_f32_split", "batched_f32", {"f32_mode": "split"}),
+                             ("mp_batched_F64_shared_phase", "mp_batched", {"resamp_factor": 64})):
+            try:
+                ln = kchain_measure(a, wl, N, 128, 64, a.kchain_steps, 3, **kw)
+                kc[name] = {"chain_it_per_s": ln["value"], "ms_per_step": ln["ms_per_step"], "steps": ln["steps"],
+                            "kernel_ms": ln["roofline"]["kernel_ms"], "roofline": ln["roofline"],
+                            "acceptance": ln["acceptance"], "config": ln["config"]}
+            except (Exception, SystemExit) as e:  # noqa: BLE001 -- a side measurement never costs the main line
+                kc[name] = {"error": str(e)}
+        out.setdefault("extra", {})["kchain"] = kc
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

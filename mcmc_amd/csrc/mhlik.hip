@@ -279,6 +279,7 @@ int fail(mhlik_ctx *c, int code, const char *fmt, ...)
 void chain_free(ChainHost &h);
 void kchain_free(KChainHost &h);
 void mpb_free(mhlik_ctx *c);
+void mpb_clear_slots(mhlik_ctx *c);
 
 struct VariantDef {
   int R, U;
@@ -1039,6 +1040,15 @@ int mhlik_comm_destroy(mhlik_ctx *c)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = g_rccl.ok ? g_rccl.CommDestroy(c->comm) : 0;
   c->comm = nullptr;
+  // From here on an evaluation writes this rank's segments only: what the last all-reduce left in the other
+  // segments' slots (device and pinned host copies) must not be added to it.
+  const size_t slot_bytes = sizeof(double) * MHLIK_MAX_BATCH * c->nseg;
+  memset(c->slots_host, 0, slot_bytes);
+  HIPCHK(c, hipMemset(c->slots_send, 0, slot_bytes));
+  HIPCHK(c, hipMemset(c->slots_recv, 0, slot_bytes));
+  mpb_clear_slots(c);
+  c->last_seg_sums.clear();
+  c->mp_last_slots.clear();
   if (rc != 0) return fail(c, MHLIK_ECOMM, "ncclCommDestroy: %s", g_rccl.GetErrorString(rc));
   return MHLIK_OK;
 }

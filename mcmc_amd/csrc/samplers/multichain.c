@@ -76,6 +76,7 @@ typedef struct {
   int32_t *choose[2];
   double *rows[2]; /* [KC_CHUNK][K][d] states after each iteration */
   uint8_t *acc[2]; /* [KC_CHUNK][K] */
+  int pin_inc[2], pin_rows[2]; /* which of inc / rows came from mhlik_host_alloc (the rest is malloc'ed) */
 } kc_buffers;
 
 /* page-locked when the library can provide it (full-rate copies), ordinary memory otherwise */
@@ -91,18 +92,17 @@ static void *kc_host(size_t bytes, int *pinned)
 }
 
 /* The chunk buffers are kept between sampler calls of the same shape (page-locked allocation costs milliseconds);
- * they are released when a call of another shape arrives, and left to the OS at exit. */
+ * they are released when a call of another shape arrives, and left to the OS at exit.  g_kc_mu guards the cache: a
+ * second caller that arrives while it is in use (another thread, a nested call) takes buffers of its own. */
 static kc_buffers g_kc;
-static int g_kc_K = 0, g_kc_d = 0, g_kc_mp = 0, g_kc_pinned = 0, g_kc_busy = 0;
+static int g_kc_K = 0, g_kc_d = 0, g_kc_mp = 0, g_kc_busy = 0;
+static pthread_mutex_t g_kc_mu = PTHREAD_MUTEX_INITIALIZER;
 
-static void kc_alloc(kc_buffers *b, int K, int d, int mp, int *pinned)
+static void kc_alloc(kc_buffers *b, int K, int d, int mp)
 {
-  int pin = 1, one;
   for (int i = 0; i < 2; i++) {
-    b->inc[i] = (double *)kc_host(sizeof(double) * (size_t)KC_CHUNK * K * d, &one);
-    pin &= one;
-    b->rows[i] = (double *)kc_host(sizeof(double) * (size_t)KC_CHUNK * K * d, &one);
-    pin &= one;
+    b->inc[i] = (double *)kc_host(sizeof(double) * (size_t)KC_CHUNK * K * d, &b->pin_inc[i]);
+    b->rows[i] = (double *)kc_host(sizeof(double) * (size_t)KC_CHUNK * K * d, &b->pin_rows[i]);
     b->u[i] = (double *)malloc(sizeof(double) * (size_t)KC_CHUNK * K);
     b->acc[i] = (uint8_t *)malloc((size_t)KC_CHUNK * K);
     b->choose[i] = mp ? (int32_t *)malloc(sizeof(int32_t) * (size_t)KC_CHUNK * K) : NULL;
@@ -111,19 +111,21 @@ static void kc_alloc(kc_buffers *b, int K, int d, int mp, int *pinned)
       exit(MHLIK_ENOMEM);
     }
   }
-  pinned[0] = pin;
 }
 
-static void kc_free(kc_buffers *b, int pinned)
+static void kc_free_one(void *p, int pinned)
+{
+  if (pinned)
+    mhlik_host_free(p);
+  else
+    free(p);
+}
+
+static void kc_free(kc_buffers *b)
 {
   for (int i = 0; i < 2; i++) {
-    if (pinned) {
-      mhlik_host_free(b->inc[i]);
-      mhlik_host_free(b->rows[i]);
-    } else {
-      free(b->inc[i]);
-      free(b->rows[i]);
-    }
+    kc_free_one(b->inc[i], b->pin_inc[i]);
+    kc_free_one(b->rows[i], b->pin_rows[i]);
     free(b->u[i]);
     free(b->acc[i]);
     free(b->choose[i]);
@@ -189,24 +191,24 @@ static void kc_run(mhlik_ctx *lik, int K, int d, gsl_rng **r, double sd, long nb
 {
   const long total = nburn + Ns;
   kc_buffers B;
-  int pinned = 0, cached = 0;
-  if (!g_kc_busy) { /* not re-entrant: a nested or concurrent call takes buffers of its own */
+  int cached = 0;
+  pthread_mutex_lock(&g_kc_mu);
+  if (!g_kc_busy) {
     if (g_kc_K && (g_kc_K != K || g_kc_d != d || g_kc_mp != (mp != NULL))) {
-      kc_free(&g_kc, g_kc_pinned);
+      kc_free(&g_kc);
       g_kc_K = 0;
     }
     if (!g_kc_K) {
-      kc_alloc(&g_kc, K, d, mp != NULL, &g_kc_pinned);
+      kc_alloc(&g_kc, K, d, mp != NULL);
       g_kc_K = K;
       g_kc_d = d;
       g_kc_mp = mp != NULL;
     }
     B = g_kc;
-    pinned = g_kc_pinned;
     g_kc_busy = cached = 1;
-  } else {
-    kc_alloc(&B, K, d, mp != NULL, &pinned);
   }
+  pthread_mutex_unlock(&g_kc_mu);
+  if (!cached) kc_alloc(&B, K, d, mp != NULL);
   kc_draw_job job[2];
   for (int i = 0; i < 2; i++) {
     job[i].K = K;
@@ -290,10 +292,13 @@ static void kc_run(mhlik_ctx *lik, int K, int d, gsl_rng **r, double sd, long nb
   const double t_last = kc_now();
   if (have_prev) kc_scatter(&sc);
   if (kc_timing) fprintf(stderr, "kc_run: last scatter %.3f ms, whole run %.3f ms\n", kc_now() - t_last, kc_now() - t_first);
-  if (cached)
+  if (cached) {
+    pthread_mutex_lock(&g_kc_mu);
     g_kc_busy = 0;
-  else
-    kc_free(&B, pinned);
+    pthread_mutex_unlock(&g_kc_mu);
+  } else {
+    kc_free(&B);
+  }
 }
 
 /* ---- the per-iteration host loop (MCMC_AMD_HOST_LOOP=1) ---- */

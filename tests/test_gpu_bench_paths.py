@@ -83,6 +83,56 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert "error" not in big and big["rows_per_gpu"] == 600000 and big["in_library_rccl"] is False
 
 
+def test_bench_eight_rank_flow_on_one_gpu():
+    """The 8-GPU node's shape rehearsed on this one GPU: `python bench.py --gpus 8` launches eight ranks itself, each
+    holds ONE of the eight row segments, all pinned to device 0 (MHLIK_BENCH_DEVICE=0).  RCCL refuses eight ranks on
+    one device, so with --allow-fallback they agree on the torch.distributed (gloo) host loop; the chain and its
+    acceptance are the single-process run's, every rank reports itself on stderr, and the N=100M-style side run shards
+    the same way."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(MHLIK_BENCH_DEVICE="0")
+    common = ["--rows", "400000", "--cols", "16", "--steps", "30", "--warmup", "5", "--cpu-iters", "0"]
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--allow-fallback", "--big-rows", "800000"] + common,
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    eight = json.loads(lines[0])
+    one = _bench_line([sys.executable, "bench.py", "--no-extras"] + common, dict(os.environ))
+    assert eight["n_gpus"] == 8 and eight["config"]["rows_per_gpu"] == 50000 and eight["rccl_ranks"] == 0
+    assert "fallback host loop" in eight["config"]["parallelism"]
+    assert eight["acceptance"] == one["acceptance"]
+    big = eight["extra"]["n100m"]
+    assert "error" not in big and big["rows_per_gpu"] == 100000 and big["in_library_rccl"] is False
+    for r in range(8):  # "bench.py: rank 3 LOCAL_RANK=3 device 0 pci ... mhlik_comm_ranks=0"
+        assert "bench.py: rank %d LOCAL_RANK=%d device 0 " % (r, r) in out.stderr, out.stderr[-3000:]
+    # the same eight ranks without the flag: non-zero, no number
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--no-extras"] + common, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=280)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    assert "in-library RCCL communicator could not be built" in bad.stderr, bad.stderr[-3000:]
+
+
+def test_default_line_carries_the_kchain_side_measurements(monkeypatch):
+    """extra.kchain (BASELINE configs[4] beside the metric) is built by kchain_measure, the function the --workload
+    runs print: three objects with chain-it/s, kernel ms and a roofline object each."""
+    import argparse
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = argparse.Namespace(seed=0, data_seed=12345, f32_mode="split", resamp_factor=16)
+    for wl, kw, bound in (("batched_f64", {}, "mfma"), ("batched_f32", {"f32_mode": "split"}, "hbm"),
+                          ("mp_batched", {"resamp_factor": 64}, "hbm")):
+        ln = bench.kchain_measure(a, wl, 200_000, 128, 64, 20, 3, **kw)
+        assert ln["metric"] == "chain_iterations_per_sec" and ln["value"] > 0 and ln["config"]["chains"] == 64
+        r = ln["roofline"]
+        assert r["bound"] == bound and r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
 def test_bench_gpus_2_launches_itself_and_fails_loudly_without_rccl():
     """`python bench.py --gpus 2`, the way the driver calls the 1-GPU run: bench.py starts torch.distributed.run
     itself as a child process.  On a one-GPU box both ranks share device 0, RCCL refuses that

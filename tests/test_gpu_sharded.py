@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_rows, align):
     import torch.distributed as dist
 
     from mcmc_amd.distributed import ShardedLikelihood
@@ -31,34 +31,46 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sl = ShardedLikelihood(N, D, transport="torch", device=0)
+    sl = ShardedLikelihood(n_rows, D, transport="torch", device=0, segment_align=align)
     sl.local.fill_synthetic(SEED)
     rng = np.random.default_rng(0)
     out = [sl.loglik(rng.normal(0, 0.05, D)) for _ in range(3)]
-    q.put((rank, out))
+    q.put((rank, out, sl.local.info()["local_rows"]))
     dist.barrier()
     sl.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_equals_single_context_bitwise(world):
-    from mcmc_amd import Likelihood
-
+def _spawn(target, world, args):
+    """`world` processes on the one GPU of the box (the parent holds no context meanwhile); their queue items sorted
+    by rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return got
+
+
+# world 8 is the target machine's shape: ONE segment per rank.  (8, 5000, 1024): segments rounded up to 1024 rows
+# cover the 5000 rows with five of them, so ranks 5, 6 and 7 hold no rows at all.
+@pytest.mark.parametrize("world,n_rows,align", [(2, N, 0), (4, N, 0), (8, N, 0), (8, 5000, 1024), (8, 9, 0)])
+def test_sharded_hip_equals_single_context_bitwise(world, n_rows, align):
+    from mcmc_amd import Likelihood
+
+    got = _spawn(_worker, world, (n_rows, align))
     for g in got[1:]:
         assert g[1] == got[0][1]
+    assert sum(g[2] for g in got) == n_rows
+    if (n_rows, align) == (5000, 1024):
+        assert [g[2] for g in got] == [1024, 1024, 1024, 1024, 904, 0, 0, 0]
     rng = np.random.default_rng(0)
-    with Likelihood(N, D, device=0) as lk:
+    with Likelihood(n_rows, D, device=0, segment_align=align) as lk:
         lk.fill_synthetic(SEED)
         for v in got[0][1]:
             assert lk.loglik(rng.normal(0, 0.05, D)) == v
@@ -88,7 +100,7 @@ def test_rccl_path_with_one_rank(monkeypatch):
 
 # ---- mixed precision over row shards ------------------------------------------------------------------------------
 MP_N, MP_D, MP_BLOCK, MP_RF, MP_EPS = 300_007, 6, 128, 4, 1.7e-7
-MP_BLOCKS = (MP_N + MP_BLOCK - 1) // MP_BLOCK + 3  # the last block is ragged and three lie beyond the data
+MP_BLOCKS = (MP_N + MP_BLOCK - 1) // MP_BLOCK + 3  # = _mp_blocks(MP_N)
 
 
 def _mp_thetas():
@@ -96,7 +108,11 @@ def _mp_thetas():
     return [rng.normal(0, 0.4, MP_D) for _ in range(5)]
 
 
-def _mp_worker(rank, world, port, q):
+def _mp_blocks(n_rows):
+    return (n_rows + MP_BLOCK - 1) // MP_BLOCK + 3  # the last block is ragged and three lie beyond the data
+
+
+def _mp_worker(rank, world, port, q, n_rows):
     import torch.distributed as dist
 
     from mcmc_amd.distributed import ShardedLikelihood
@@ -104,10 +120,11 @@ def _mp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sl = ShardedLikelihood(MP_N, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
+    blocks = _mp_blocks(n_rows)
+    sl = ShardedLikelihood(n_rows, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
     sl.local.fill_synthetic(SEED)
-    sl.mp_reset(MP_BLOCK, MP_BLOCKS)
-    out = [sl.mp_loglik(th, MP_BLOCK, MP_BLOCKS, MP_RF, call % MP_RF, 1234, call, MP_EPS)
+    sl.mp_reset(MP_BLOCK, blocks)
+    out = [sl.mp_loglik(th, MP_BLOCK, blocks, MP_RF, call % MP_RF, 1234, call, MP_EPS)
            for call, th in enumerate(_mp_thetas())]
     q.put((rank, out))
     dist.barrier()
@@ -115,8 +132,9 @@ def _mp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_mixed_precision_equals_single_context_bitwise(world):
+# (8, 5000): five 1024-row segments hold the rows, ranks 5-7 hold none (and the blocks beyond the data go to rank 7)
+@pytest.mark.parametrize("world,n_rows", [(2, MP_N), (4, MP_N), (8, MP_N), (8, 5000)])
+def test_sharded_mixed_precision_equals_single_context_bitwise(world, n_rows):
     """mhlik_mp_loglik over row shards (the reference's mixed-precision path is single-GPU, mcmc_mp.cu:286): with
     block-aligned segments every rank evaluates the data blocks of its own rows, and values, bright and dark counts of
     a whole call sequence -- the indicators evolve from call to call -- are those of the single-context run, bit for
@@ -127,34 +145,26 @@ def test_sharded_mixed_precision_equals_single_context_bitwise(world):
     from mcmc_amd import Likelihood
     from mcmc_amd.likelihood import synthetic_host
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_mp_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = _spawn(_mp_worker, world, (n_rows,))
     for g in got[1:]:
         assert g[1] == got[0][1]
-    X = synthetic_host(SEED, MP_N, MP_D)
+    blocks = _mp_blocks(n_rows)
+    X = synthetic_host(SEED, n_rows, MP_D)
     Xf = np.asfortranarray(X.astype(np.float32))
     L = O.lib()
     L.oracle_mp_likelihood.restype = C.c_double
     L.oracle_mp_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    z = np.ones(MP_BLOCKS, dtype=np.int8)
-    with Likelihood(MP_N, MP_D, precision=3, device=0, segment_align=1024) as lk:  # 8 segments, one GPU
+    z = np.ones(blocks, dtype=np.int8)
+    with Likelihood(n_rows, MP_D, precision=3, device=0, segment_align=1024) as lk:  # 8 segments, one GPU
         lk.fill_synthetic(SEED)
-        lk.mp_reset(MP_BLOCK, MP_BLOCKS)
+        lk.mp_reset(MP_BLOCK, blocks)
         for call, th in enumerate(_mp_thetas()):
-            one = lk.mp_loglik(th, MP_BLOCK, MP_BLOCKS, MP_RF, call % MP_RF, 1234, call, MP_EPS)
+            one = lk.mp_loglik(th, MP_BLOCK, blocks, MP_RF, call % MP_RF, 1234, call, MP_EPS)
             assert one == got[0][1][call], (call, one, got[0][1][call])
             nb, nd = C.c_int(), C.c_int()
-            want = L.oracle_mp_likelihood(O.ptr(X), O.ptr(Xf), MP_N, MP_D, MP_N, O.ptr(th), MP_BLOCK, MP_BLOCKS, MP_RF,
+            want = L.oracle_mp_likelihood(O.ptr(X), O.ptr(Xf), n_rows, MP_D, n_rows, O.ptr(th), MP_BLOCK, blocks, MP_RF,
                                           call % MP_RF, 1234, call, MP_EPS, O.ptr(z), C.byref(nb), C.byref(nd))
             assert (one[1], one[2]) == (nb.value, nd.value), (call, one, nb.value, nd.value)
             assert abs(one[0] - want) <= 2e-6 * abs(want)
@@ -162,7 +172,7 @@ def test_sharded_mixed_precision_equals_single_context_bitwise(world):
     eps = C.c_double()
     L.oracle_mp_bound.restype = C.c_double
     L.oracle_mp_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.POINTER(C.c_double)]
-    want_s = L.oracle_mp_bound(O.ptr(X), O.ptr(Xf), MP_N, MP_D, MP_N, O.ptr(_mp_thetas()[0]), C.byref(eps))
+    want_s = L.oracle_mp_bound(O.ptr(X), O.ptr(Xf), n_rows, MP_D, n_rows, O.ptr(_mp_thetas()[0]), C.byref(eps))
     assert abs(s_all - want_s) <= 1e-10 * abs(want_s) and abs(e_all - eps.value) <= 1e-9
 
 
@@ -204,9 +214,9 @@ def _kmp_inputs():
     return thetas, phases, seeds
 
 
-def _kmp_run(obj):
+def _kmp_run(obj, n_rows=MP_N):
     thetas, phases, seeds = _kmp_inputs()
-    obj.mp_reset_batched(MP_BLOCK, MP_BLOCKS, KMP_K)
+    obj.mp_reset_batched(MP_BLOCK, _mp_blocks(n_rows), KMP_K)
     out = []
     for call in range(len(thetas)):
         v, nb, nd = obj.mp_loglik_batched(thetas[call], MP_RF, phases[call], seeds, call, MP_EPS)
@@ -214,7 +224,7 @@ def _kmp_run(obj):
     return out
 
 
-def _kmp_worker(rank, world, port, q, f32_mode):
+def _kmp_worker(rank, world, port, q, f32_mode, n_rows):
     import torch.distributed as dist
 
     from mcmc_amd.distributed import ShardedLikelihood
@@ -222,45 +232,38 @@ def _kmp_worker(rank, world, port, q, f32_mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sl = ShardedLikelihood(MP_N, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
+    sl = ShardedLikelihood(n_rows, MP_D, precision=3, transport="torch", device=0, segment_align=1024)
     sl.local.fill_synthetic(SEED)
     sl.local.set_batched_f32_mode(f32_mode)
-    q.put((rank, _kmp_run(sl)))
+    q.put((rank, _kmp_run(sl, n_rows)))
     dist.barrier()
     sl.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,f32_mode", [(2, "split"), (4, "exact")])
-def test_sharded_kchain_mixed_precision_equals_single_context_bitwise(world, f32_mode, monkeypatch):
+@pytest.mark.parametrize("world,f32_mode,n_rows", [(2, "split", MP_N), (4, "exact", MP_N), (8, "split", MP_N),
+                                                    (8, "exact", 5000)])
+def test_sharded_kchain_mixed_precision_equals_single_context_bitwise(world, f32_mode, n_rows, monkeypatch):
     """mhlik_mp_loglik_batched over row shards: every rank corrects and resamples the data blocks of its own rows
     (per-chain phases and one shared phase, i.e. both correction kernels), the K x 4 x segments slots are summed over
     the ranks, and values, bright and dark counts of a call sequence equal the single-context run with the same
     eight segments bit for bit -- which in turn matches the one-segment path of tests/test_gpu_mp_batched.py in its
     indicators exactly and in its values to float-sum tolerance, and runs unchanged over a forced one-rank RCCL
-    communicator (in-stream all-reduce + mpb_combine_kernel)."""
+    communicator (in-stream all-reduce + mpb_combine_kernel).  World 8 = one segment per rank; with 5000 rows the
+    last three ranks hold none."""
     from mcmc_amd import Likelihood
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_kmp_worker, args=(r, world, port, q, f32_mode)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = _spawn(_kmp_worker, world, (f32_mode, n_rows))
     for g in got[1:]:
         assert g[1] == got[0][1]
 
     def single(segments, align, force=False):
-        with Likelihood(MP_N, MP_D, precision=3, device=0, segments=segments, segment_align=align) as lk:
+        with Likelihood(n_rows, MP_D, precision=3, device=0, segments=segments, segment_align=align) as lk:
             lk.fill_synthetic(SEED)
             lk.set_batched_f32_mode(f32_mode)
             if force:
                 lk.comm_init(Likelihood.make_comm_id())
-            return _kmp_run(lk)
+            return _kmp_run(lk, n_rows)
 
     eight = single(8, 1024)
     assert eight == got[0][1]
@@ -271,6 +274,43 @@ def test_sharded_kchain_mixed_precision_equals_single_context_bitwise(world, f32
     monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
     assert single(8, 1024, force=True) == eight
     assert single(1, 0, force=True) == one  # one segment through the slot path: the same sums
+
+
+def test_sharded_device_loops_refuse_to_run_without_a_communicator():
+    """A context that holds only part of the segments and has no RCCL communicator (gloo transport, or after
+    mhlik_comm_destroy) cannot run the device-resident loops: their accept tests would see this rank's share of the
+    likelihood only.  Both loops say so instead of letting the ranks' chains part."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd._lib import MhlikError
+
+    with Likelihood(MP_N, MP_D, precision=3, device=0, rank=1, world=2, segment_align=1024) as lk:
+        lk.fill_synthetic(SEED)
+        assert lk.loglik(np.zeros(MP_D)) < 0  # the blocking call hands out the rank's share, as documented
+        with pytest.raises(MhlikError, match="needs mhlik_comm_init"):
+            lk.chain_begin(np.zeros(MP_D), 10.0)
+        with pytest.raises(MhlikError, match="needs mhlik_comm_init"):
+            lk.chain_resume(np.zeros(MP_D), -1.0, 10.0)
+        with pytest.raises(MhlikError, match="needs mhlik_comm_init"):
+            lk.kchain_begin(np.zeros((4, MP_D)), 10.0)
+        with pytest.raises(MhlikError, match="needs mhlik_comm_init"):
+            lk.kchain_resume(np.zeros((4, MP_D)), np.zeros(4), 10.0, mode=2)
+
+
+def test_comm_destroy_leaves_no_stale_slots(monkeypatch):
+    """mhlik_comm_destroy: later evaluations are this context's rows again, with nothing left over from the last
+    reduced call in the slot buffers (one-rank communicator: all that a one-GPU box can build)."""
+    from mcmc_amd import Likelihood
+
+    monkeypatch.setenv("MHLIK_FORCE_COMM", "1")
+    th = np.full(D, 0.01)
+    with Likelihood(100_000, D, device=0) as lk:
+        lk.fill_synthetic(SEED)
+        lk.comm_init(Likelihood.make_comm_id())
+        assert lk.comm_ranks() == 1
+        reduced = lk.loglik(th)
+        lk.comm_destroy()
+        assert lk.comm_ranks() == 0 and not lk.segment_sums().any()
+        assert lk.loglik(th) == reduced and lk.segment_sums().sum() != 0
 
 
 @pytest.mark.parametrize("N", [5000, 1024, 700])

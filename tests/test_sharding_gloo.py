@@ -19,10 +19,10 @@ N, D, SEED = 30011, 6, 21
 class OracleShard:
     """Stands in for mcmc_amd.Likelihood on a machine without a GPU."""
 
-    def __init__(self, n_rows, n_cols, precision=1, rank=0, world=1, segments=8, device=-1):
+    def __init__(self, n_rows, n_cols, precision=1, rank=0, world=1, segments=8, device=-1, segment_align=0):
         self.segments = segments
-        self.begin, self.rows, self.segs = shard_rows(n_rows, rank, world, segments)
-        self.seg_rows = segment_rows(n_rows, segments)
+        self.begin, self.rows, self.segs = shard_rows(n_rows, rank, world, segments, segment_align or 1)
+        self.seg_rows = segment_rows(n_rows, segments, segment_align or 1)
         self.X = synthetic_host(SEED, n_rows, n_cols, self.begin, self.rows)
         self._last = np.zeros(segments)
 
@@ -49,7 +49,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, align):
     import torch.distributed as dist
 
     from mcmc_amd.distributed import ShardedLikelihood
@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sl = ShardedLikelihood(N, D, transport="torch", local_factory=OracleShard)
+    sl = ShardedLikelihood(N, D, transport="torch", local_factory=OracleShard, segment_align=align)
     out = []
     rng = np.random.default_rng(0)
     for _ in range(3):
@@ -68,12 +68,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_sum_is_world_invariant(world):
+# world 8 = one segment per rank (the 8-GPU node); align 8192: four segments hold all 30011 rows, ranks 4-7 hold none
+@pytest.mark.parametrize("world,align", [(2, 0), (4, 0), (8, 0), (8, 8192)])
+def test_sharded_sum_is_world_invariant(world, align):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, align)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in procs)
@@ -84,11 +85,13 @@ def test_sharded_sum_is_world_invariant(world):
     assert got[0][1] == 0 and sum(g[2] for g in got) == N
     for a, b in zip(got, got[1:]):
         assert a[1] + a[2] == b[1]
+    if align == 8192:
+        assert [g[2] for g in got] == [8192, 8192, 8192, 30011 - 3 * 8192, 0, 0, 0, 0]
     # every rank has the same bits
     for g in got[1:]:
         assert g[3] == got[0][3]
     # and they equal the single-process sum in segment order (world = 1)
-    single = OracleShard(N, D)
+    single = OracleShard(N, D, segment_align=align)
     rng = np.random.default_rng(0)
     X = synthetic_host(SEED, N, D)
     for v in got[0][3]:
@@ -104,11 +107,13 @@ def test_segment_geometry():
         assert sum(r for _, r in rows) == n
         assert all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(7))
         for world in (1, 2, 4, 8):
-            tot = 0
-            for r in range(world):
-                b, c, segs = shard_rows(n, r, world, 8)
-                assert b == rows[segs[0]][0]
-                tot += c
-            assert tot == n
+            for align in (1, 1024):
+                arows = segment_rows(n, 8, align)
+                tot = 0
+                for r in range(world):
+                    b, c, segs = shard_rows(n, r, world, 8, align)
+                    assert b == arows[segs[0]][0]
+                    tot += c
+                assert tot == n
     with pytest.raises(ValueError):
         shard_rows(100, 0, 3, 8)
