@@ -50,7 +50,7 @@ def parse():
                     help="--gpus N>1: if the in-library RCCL communicator cannot be built, time the Python host loop that "
                          "all-reduces through torch.distributed instead of exiting non-zero (rehearsals on a one-GPU box)")
     ap.add_argument("--no-kchain", action="store_true", help="skip the BASELINE configs[4] side measurements (extra.kchain)")
-    ap.add_argument("--kchain-steps", type=int, default=100, help="lock-step iterations of each extra.kchain measurement")
+    ap.add_argument("--kchain-steps", type=int, default=200, help="lock-step iterations of each extra.kchain measurement")
     ap.add_argument("--contested-iters", type=int, default=60,
                     help="MH iterations of the contested-decision parity check of the cpu_baseline leg (0 = skip)")
     return ap.parse_args()

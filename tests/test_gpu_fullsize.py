@@ -128,3 +128,35 @@ def test_mp_batched_at_n10m_d128():
         # against double precision: the augmented likelihood is within the float pass's error of it
         dp = lk.loglik_batched(Ths[2], dtype=np.float64)
         assert np.max(np.abs(got[2][0] - dp) / np.abs(dp)) <= 1e-4
+
+
+@pytest.mark.parametrize("f32_mode", ["split", "exact"])
+def test_mp_batched_k64_shared_phase_at_n10m_d128(f32_mode):
+    """BASELINE configs[4] at its full shape, the way `bench.py --workload mp_batched` (and extra.kchain of the default
+    line) runs it: K = 64 chains on ONE shared re-examination phase, F = 64 -- i.e. mpb_dark_x3_kernel (split) /
+    mpb_dark_kernel (exact) + mpb_fix_dense_kernel + mpb_final_kernel.  Three calls (the indicators evolve); chains
+    0, 31 and 63 against the single-chain mhlik_mp_loglik sequence (the definition of mcmc_mp.cu:475-552 per chain:
+    counts identical, value within 2e-6) and the last call against the double-precision K-chain pass (1e-4)."""
+    from mcmc_amd import Likelihood
+
+    N, d, K, F, eps = 10_000_000, 128, 64, 64, 1.7e-7
+    blocks = N // 64
+    rng = np.random.default_rng(4)
+    Ths = [rng.normal(0, 0.01, (K, d)) for _ in range(3)]
+    phases = [int(rng.integers(0, F)) for _ in range(3)]
+    seeds = (1234 + np.arange(K)).astype(np.uint64)
+    with Likelihood(N, d, precision=3, segments=1) as lk:
+        lk.fill_synthetic(SEED)
+        lk.set_batched_f32_mode(f32_mode)
+        lk.mp_reset_batched(64, blocks, K)
+        got = [lk.mp_loglik_batched(Ths[c], F, np.full(K, phases[c], dtype=np.int32), seeds, c, eps) for c in range(3)]
+        assert np.all(got[0][1] + got[0][2] == blocks)
+        assert np.all(got[2][1] < blocks // 100)  # steady state: nearly every block dark
+        for k in (0, 31, 63):
+            lk.mp_reset(64, blocks)
+            for c in range(3):
+                v, nb, nd = lk.mp_loglik(Ths[c][k], 64, blocks, F, phases[c], int(seeds[k]), c, eps)
+                assert (got[c][1][k], got[c][2][k]) == (nb, nd), (c, k)
+                assert abs(got[c][0][k] - v) <= 2e-6 * abs(v), (c, k)
+        dp = lk.loglik_batched(Ths[2], dtype=np.float64)
+        assert np.max(np.abs(got[2][0] - dp) / np.abs(dp)) <= 1e-4
