@@ -175,3 +175,28 @@ def cpu_sampler(X, seed, Ns, burnin, rwsd, theta0=None, trace=True):
     L.cpu_sampler(data, rng.r, mcin, mct, mcdata, C.byref(res))
     n = L.oracle_trace_end() if trace else 0
     return dict(samples=samples, burn=burn, acceptance=res.acceptance, trace=tr[:n], res=res)
+
+
+def sp_sampler_forced(seed, d, rwsdf, burnin, Ns, lik, theta0=None):
+    """oracle_sp_sampler (oracle/sp_path.c): the single-precision sampler's host arithmetic with the float
+    likelihoods fed by the caller (lik[0] = chain start, then one per iteration).  Returns dict(samples, burn,
+    proposals, accepted, cposterior, trace)."""
+    L = lib()
+    L.oracle_sp_sampler.restype = C.c_long
+    L.oracle_sp_sampler.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_long]
+    lik = np.ascontiguousarray(lik, dtype=np.float32)
+    assert len(lik) == burnin + Ns and burnin >= 1
+    samples = np.zeros((Ns, d), dtype=np.float32)
+    burn = np.zeros((burnin, d), dtype=np.float32)
+    if theta0 is not None:
+        burn[0, :] = theta0
+    n = burnin - 1 + Ns
+    props = np.zeros((n, d), dtype=np.float32)
+    tr = np.zeros(n, dtype=TRACE_DTYPE)
+    acc, cp = C.c_int(0), C.c_float(0)
+    rng = Rng(seed, L)
+    got = L.oracle_sp_sampler(rng.r, d, float(rwsdf), burnin, Ns, ptr(lik), ptr(burn), ptr(samples), ptr(props),
+                              C.byref(acc), C.byref(cp), ptr(tr), n)
+    assert got == n
+    return dict(samples=samples, burn=burn, proposals=props, accepted=acc.value, cposterior=cp.value, trace=tr)

@@ -251,3 +251,51 @@ def test_log_likelihood_sees_a_matrix_refilled_in_place():
     want, _ = O.log_likelihood(X, th)
     got = S.log_likelihood(X, th)
     assert abs(got - want) <= 1e-10 * abs(want)
+
+
+@pytest.mark.parametrize("host_loop", [False, True])
+@pytest.mark.parametrize("N,d,scale", [(10000, 3, 0.3), (40000, 16, 0.05), (20000, 64, 0.02)])
+def test_sp_sampler_host_arithmetic_against_teacher_forced_oracle(monkeypatch, N, d, scale, host_loop):
+    """sp_sampler's arithmetic AROUND the likelihood (mcmc_gpu_sp.cu:86-177, 561-580: float state and proposals, float
+    prior accumulator over double log(pdf) terms, float posterior and ratio, logf(uf) <= ratio, rows written) against
+    an independent restatement, oracle/sp_path.c.  In float the N-term sum legitimately depends on the order, so the
+    oracle is fed the product's float likelihoods ("teacher forcing") and each fed value is checked against the DP
+    oracle at the ORACLE's own proposal (1e-4): a product whose state, stream or proposals differed would feed
+    likelihoods of other points."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd import samplers as S
+    from mcmc_amd.likelihood import synthetic_host
+
+    if host_loop:
+        monkeypatch.setenv("MCMC_AMD_HOST_LOOP", "1")
+    X = synthetic_host(4242, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    Ns, burnin, seed = 120, 40, 9
+    rwsdf = 2.38 / np.sqrt(d) * scale
+    theta0 = np.random.default_rng(1).normal(0, 0.05, d).astype(np.float32)
+    with Likelihood(N, d, precision=2) as lf:
+        lf.upload(Xf)
+        lik0 = lf.loglik_f32(theta0)
+        with S.attached(lf):
+            got = S.sp_sampler(None, seed, Ns, burnin, rwsdf, theta0=theta0, n_rows=N, n_cols=d)
+    gt = got["trace"]
+    assert len(gt) == burnin - 1 + Ns
+    feed = np.concatenate([[lik0], gt["lik"]]).astype(np.float32)
+    assert np.array_equal(feed[1:].astype(np.float64), gt["lik"])  # the trace holds float values
+    ref = O.sp_sampler_forced(seed, d, rwsdf, burnin, Ns, feed, theta0=theta0)
+    rt = ref["trace"]
+    assert np.array_equal(rt["logu"], gt["logu"])
+    assert np.array_equal(rt["accept"], gt["accept"]) and 0 < rt["accept"].sum() < len(rt)
+    if host_loop:
+        assert np.array_equal(rt["ratio"], gt["ratio"])
+    else:  # the device's double log(pdf) may differ from glibc's in the last place: at most one float ulp of the ratio
+        assert np.allclose(rt["ratio"], gt["ratio"], rtol=2.4e-7, atol=0)
+    assert np.array_equal(ref["samples"], got["samples"])
+    assert np.array_equal(ref["burn"], got["burn"])
+    assert ref["accepted"] == int(round(got["acceptance"] * Ns))
+    # every fed likelihood is the likelihood of the oracle's own proposal
+    for i in range(len(rt)):
+        dp, _ = O.log_likelihood(X, ref["proposals"][i].astype(np.float64))
+        assert abs(float(feed[i + 1]) - dp) <= REL_TOL_SP * abs(dp), i
+    dp0, _ = O.log_likelihood(X, theta0.astype(np.float64))
+    assert abs(lik0 - dp0) <= REL_TOL_SP * abs(dp0)

@@ -224,3 +224,59 @@ def test_golden_mp_and_chain_statistics():
                    O.mcmc_str(ddata=t["d"], Nd=t["N"], Ns=1, burnin=t["burnin"], impl=0), C.byref(mct), O.ptr(init),
                    t["length"])
     assert mct.rwsd == fh(t["rwsd_out"])
+
+
+def test_sp_sampler_restatement_against_numpy_float32_loop():
+    """oracle_sp_sampler (oracle/sp_path.c) against a second statement of mcmc_gpu_sp.cu:86-177,561-580 in numpy
+    float32 scalars, on a likelihood feed from the reference-order float oracle: the types are the point (float state,
+    float accumulator += double term, float ratio, logf of the float uniform)."""
+    N, d, burnin, Ns, seed = 3000, 5, 12, 40, 4
+    rwsdf = np.float32(0.05)
+    X = synthetic_host(77, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    L = O.lib()
+    L.gsl_ran_gaussian_ziggurat.restype = C.c_double
+    L.gsl_ran_gaussian_ziggurat.argtypes = [C.c_void_p, C.c_double]
+    L.gsl_rng_uniform.restype = C.c_double
+    L.gsl_rng_uniform.argtypes = [C.c_void_p]
+    L.gsl_ran_gaussian_pdf.restype = C.c_double
+    L.gsl_ran_gaussian_pdf.argtypes = [C.c_double, C.c_double]
+    scratch = np.empty(N, dtype=np.float32)
+
+    def lik_f(th):
+        th = np.ascontiguousarray(th, dtype=np.float32)
+        return np.float32(L.oracle_gpu_likelihood_f(O.ptr(Xf), N, d, N, O.ptr(th), O.ptr(scratch), 256, 32))
+
+    def prior(th):
+        acc = np.float32(0)
+        for x in th:
+            acc = np.float32(np.float64(acc) + np.log(L.gsl_ran_gaussian_pdf(float(x), 10.0)))
+        return acc
+
+    rng = O.Rng(seed, L)
+    cur = np.zeros(d, dtype=np.float32)
+    feed = [lik_f(cur)]
+    cpost = np.float32(prior(cur) + feed[0])
+    rows, trace = [], []
+    for i in range(burnin - 1 + Ns):
+        prop = np.array([np.float32(cur[j] + np.float32(L.gsl_ran_gaussian_ziggurat(rng.r, float(rwsdf))))
+                         for j in range(d)], dtype=np.float32)
+        pl = lik_f(prop)
+        feed.append(pl)
+        ppost = np.float32(prior(prop) + pl)
+        ratio = np.float32(ppost - cpost)
+        with np.errstate(divide="ignore"):
+            logu = np.log(np.float32(L.gsl_rng_uniform(rng.r)))  # float32 in, float32 log
+        a = bool(logu <= ratio)
+        if a:
+            cur, cpost = prop, ppost
+        rows.append(cur.copy())
+        trace.append((float(ratio), a))
+    ref = O.sp_sampler_forced(seed, d, rwsdf, burnin, Ns, np.array(feed, dtype=np.float32))
+    assert [bool(x) for x in ref["trace"]["accept"]] == [a for _, a in trace]
+    assert np.array_equal(ref["trace"]["ratio"], np.array([r for r, _ in trace]))
+    assert np.array_equal(ref["burn"][1:], np.array(rows[:burnin - 1]))
+    assert np.array_equal(ref["samples"], np.array(rows[burnin - 1:]))
+    assert np.array_equal(ref["proposals"][0], rows[0] if trace[0][1] else ref["proposals"][0])
+    assert 0 < sum(a for _, a in trace) < len(trace)
+    assert ref["cposterior"] == float(cpost)
