@@ -123,6 +123,10 @@ void mcmc_amd_mp_multichain_sampler(mhlik_ctx *lik, int K, gsl_rng **r, mp_str *
 void mcmc_amd_attach_context(mhlik_ctx *lik);
 mhlik_ctx *mcmc_amd_attached_context(void);
 
+/* log_likelihood (mcmc_cpu.h:34) without an attached context keeps its device buffers between calls of one shape;
+ * this releases them.  Nothing is released from an exit handler: what is still held at exit is left to the OS. */
+void mcmc_amd_release_cached(void);
+
 /* Per-iteration record of the MH loops (every loop appends while tracing). */
 typedef struct {
   double lik;   /* L(theta') */

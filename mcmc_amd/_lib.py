@@ -190,6 +190,17 @@ def load_mhlik():
             "mcmc_amd: %s not found -- the MI355X likelihood path has no CPU fallback; "
             "build it with `make -C mcmc_amd/csrc`" % path
         )
+    # PyTorch wheels bundle their own HIP runtime and RCCL (torch 2.10+rocm7.0 here, beside ROCm 7.2 in /opt/rocm).
+    # Whichever copy a process loads FIRST serves every later DT_NEEDED / dlopen of the same soname, so a process that
+    # loads this library, creates a context and only then imports torch ends up with two runtimes: RCCL then fails
+    # ("ncclCommInitRank: unhandled cuda error") or the process aborts at exit ("double free or corruption").  The
+    # Python layer uses torch.distributed as its control plane anyway, so it settles the order here: torch first.
+    # MCMC_AMD_NO_TORCH=1 skips this (a process that never imports torch; the C drivers never do).
+    if os.environ.get("MCMC_AMD_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, res, args in _SIGS:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

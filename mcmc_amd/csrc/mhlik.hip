@@ -125,6 +125,8 @@ struct Store {
   int32_t *tile_valid = nullptr;           // device [ntiles]
   int64_t *tile_row0 = nullptr;            // device [ntiles], global row of the tile's first row
   SegDesc *segs = nullptr;                 // device [nseg_local]
+  PersistJob *pjobs = nullptr;             // device [npjobs]: the (segment, lane) jobs of the persistent chain kernel
+  int npjobs = 0;
   std::vector<int32_t> h_valid;
   std::vector<int64_t> h_row0;
   std::vector<SegDesc> h_segs;
@@ -147,6 +149,7 @@ struct ChainSlot {
   int64_t n = 0;                                        // the batch in flight
   int pairs = 0;
   bool want_samples = false;
+  bool persist = false;                                 // ran as ONE persistent launch: pairs == 1 brackets all n iterations
 };
 struct ChainHost {
   ChainHdr *hdr = nullptr;
@@ -161,6 +164,8 @@ struct ChainHost {
   bool load_state = false, host_state_valid = false;
   ChainHdr host_hdr;
   std::vector<unsigned char> host_cur;
+  unsigned char *persist_words = nullptr; // device: [abort word, 16 B][2][2 * kPersistMaxJobs] granules
+  int persist_blocks_per_cu[2] = {0, 0};  // occupancy of chain_persist_kernel<double / float>, looked up once
 };
 
 // K lock-step chains on the device (mhlik_kchain.hpp): states + one batch of buffers.
@@ -367,6 +372,24 @@ template <typename T> int build_store(mhlik_ctx *c)
     HIPCHK(c, hipMalloc((void **)&s.segs, sizeof(SegDesc) * s.h_segs.size()));
     HIPCHK(c, hipMemcpy(s.segs, s.h_segs.data(), sizeof(SegDesc) * s.h_segs.size(), hipMemcpyHostToDevice));
   }
+  // jobs of the persistent chain kernel: lane i of segment g's sum owns that segment's tiles i, i+64, ...
+  // (ordered lane-major, so that a grid of W workgroups taking jobs w, w+W, ... spreads every segment)
+  s.npjobs = 0;
+  if ((int)c->segs.size() == c->nseg && c->nseg <= kPersistMaxSeg && s.ntiles > 0) {
+    std::vector<PersistJob> jobs;
+    for (int lane = 0; lane < kWave; lane++)
+      for (const SegDesc &sd : s.h_segs)
+        if (sd.tile_count > lane) {
+          PersistJob j;
+          j.first_tile = sd.tile_begin + lane;
+          j.ntiles = (int32_t)((sd.tile_count - lane + kWave - 1) / kWave);
+          j.pub_idx = sd.global_index * kWave + lane;
+          jobs.push_back(j);
+        }
+    HIPCHK(c, hipMalloc((void **)&s.pjobs, sizeof(PersistJob) * jobs.size()));
+    HIPCHK(c, hipMemcpy(s.pjobs, jobs.data(), sizeof(PersistJob) * jobs.size(), hipMemcpyHostToDevice));
+    s.npjobs = (int)jobs.size();
+  }
   c->hbm_bytes += s.bytes;
 
   // partial-sum scratch: one double per tile per chain
@@ -386,6 +409,7 @@ void free_store(Store &s)
   if (s.tile_valid) (void)hipFree(s.tile_valid);
   if (s.tile_row0) (void)hipFree(s.tile_row0);
   if (s.segs) (void)hipFree(s.segs);
+  if (s.pjobs) (void)hipFree(s.pjobs);
   s = Store();
 }
 

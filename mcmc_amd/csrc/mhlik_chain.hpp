@@ -82,36 +82,20 @@ template <typename T> __global__ __launch_bounds__(kBlock) void chain_propose_ke
   for (int k = threadIdx.x; k < c.d; k += kBlock) prop[k] = cur[k] + inc[(int64_t)it * c.d + k];
 }
 
+// What follows the segment sums in one iteration, shared by the step kernel (state in global memory) and the
+// persistent kernel (every workgroup keeps its own copy of the state in LDS and runs this redundantly: the same
+// instructions on the same numbers, hence the same bits everywhere).
+//   slots     LDS, the nseg per-segment sums (written before the call; the first barrier in here orders them)
+//   terms     LDS scratch, kPriorChunk doubles;  s_accept  LDS word
+//   h, cur, prop   the chain state this workgroup reads and updates
+//   write_out  whether this workgroup files the iteration's outputs (lik, ratio, acc, sample row)
 // mode 0: MH iteration `it` (0 <= it < c.n) of the batch
 // mode 1: chain start -- the pass was over prop = theta0: cur = prop,
 //         cposterior = prior + L; nothing is written to the batch outputs
-//
-// slots_in != nullptr: the per-segment sums are there already (after the
-// segment kernel and, with several GPUs, the all-reduce).  Otherwise this
-// kernel adds the tile partials itself, one wave per segment, with the same
-// code and therefore the same bits as segment_sum_kernel (needs every segment
-// local and nseg <= waves of the workgroup).
 template <typename T>
-__global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int it, int mode,
-                                                               const double *__restrict__ slots_in, int nseg,
-                                                               const double *__restrict__ partials,
-                                                               const SegDesc *__restrict__ segs)
+__device__ __forceinline__ void chain_decide(const ChainDev &c, int it, int mode, const double *slots, int nseg,
+                                             double *terms, int *s_accept, ChainHdr *h, T *cur, T *prop, bool write_out)
 {
-  __shared__ double slots[kMaxSegmentsDev];
-  __shared__ double terms[kPriorChunk];
-  __shared__ int s_accept;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  if (!slots_in) {
-    if (wave < nseg) {
-      const SegDesc sd = segs[wave];
-      const double v = wave_sum_lane63(strided_sum<kWave>(partials + sd.tile_begin, lane, sd.tile_count));
-      if (lane == kWave - 1) slots[sd.global_index] = v;
-    }
-  } else if ((int)threadIdx.x < nseg) {
-    slots[threadIdx.x] = slots_in[threadIdx.x];
-  }
-
-  T *cur = (T *)c.cur, *prop = (T *)c.prop;
   const int d = c.d;
   // prior: the terms in parallel, then added in column order like the host
   // loop does (float chain: a float accumulator += a double term)
@@ -139,11 +123,10 @@ __global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int i
     for (int g = 0; g < nseg; g++) total += slots[g];
     const T L = (T)total;
     const T ppost = prior + L;
-    ChainHdr *h = c.hdr;
     if (mode == 1) {
       h->cpost = (double)ppost;
       h->accepted = 0;
-      s_accept = 1;
+      *s_accept = 1;
     } else {
       const T ratio = ppost - (T)h->cpost;
       const T logu = ((const T *)c.logu)[it];
@@ -152,27 +135,195 @@ __global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int i
         h->cpost = (double)ppost;
         h->accepted += 1;
       }
-      c.lik[it] = (double)L;
-      c.ratio[it] = (double)ratio;
-      c.acc[it] = (unsigned char)a;
-      s_accept = a;
+      if (write_out) {
+        c.lik[it] = (double)L;
+        c.ratio[it] = (double)ratio;
+        c.acc[it] = (unsigned char)a;
+      }
+      *s_accept = a;
     }
   }
   __syncthreads();
-  const bool accept = s_accept != 0;
+  const bool accept = *s_accept != 0;
   const T *inc = (const T *)c.inc;
   T *samples = (T *)c.samples;
-  const bool last = mode == 0 && it + 1 == c.n && c.cur_out != nullptr;
   for (int k = threadIdx.x; k < d; k += blockDim.x) {
     const T x = accept ? prop[k] : cur[k];
     if (accept) cur[k] = x;
     if (mode == 0) {
-      if (samples) samples[(int64_t)it * d + k] = x;
+      if (samples && write_out) samples[(int64_t)it * d + k] = x;
       if (it + 1 < c.n) prop[k] = x + inc[(int64_t)(it + 1) * d + k];
-      if (last) ((T *)c.cur_out)[k] = x;
     }
   }
-  if (last && threadIdx.x == 0) *c.hdr_out = *c.hdr; // thread 0 wrote the header above
+}
+
+// slots_in != nullptr: the per-segment sums are there already (after the
+// segment kernel and, with several GPUs, the all-reduce).  Otherwise this
+// kernel adds the tile partials itself, one wave per segment, with the same
+// code and therefore the same bits as segment_sum_kernel (needs every segment
+// local and nseg <= waves of the workgroup).
+template <typename T>
+__global__ __launch_bounds__(kSegBlock) void chain_step_kernel(ChainDev c, int it, int mode,
+                                                               const double *__restrict__ slots_in, int nseg,
+                                                               const double *__restrict__ partials,
+                                                               const SegDesc *__restrict__ segs)
+{
+  __shared__ double slots[kMaxSegmentsDev];
+  __shared__ double terms[kPriorChunk];
+  __shared__ int s_accept;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (!slots_in) {
+    if (wave < nseg) {
+      const SegDesc sd = segs[wave];
+      const double v = wave_sum_lane63(strided_sum<kWave>(partials + sd.tile_begin, lane, sd.tile_count));
+      if (lane == kWave - 1) slots[sd.global_index] = v;
+    }
+  } else if ((int)threadIdx.x < nseg) {
+    slots[threadIdx.x] = slots_in[threadIdx.x];
+  }
+  T *cur = (T *)c.cur, *prop = (T *)c.prop;
+  chain_decide<T>(c, it, mode, slots, nseg, terms, &s_accept, c.hdr, cur, prop, true);
+  // the batch's last iteration leaves a copy of the state at the head of the download image
+  if (mode == 0 && it + 1 == c.n && c.cur_out != nullptr) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < c.d; k += blockDim.x) ((T *)c.cur_out)[k] = cur[k];
+    if (threadIdx.x == 0) *c.hdr_out = *c.hdr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The whole batch in ONE launch, for matrices small enough that two dependent dispatches per iteration are what an
+// iteration costs (BASELINE configs[0] and [1]: the reference runs them 3000 x 40000 iterations,
+// scr/sh_scr/multiple_runs_gpu.sh:3-6).  Work unit = job (segment s, lane i): the tiles i, i+64, ... of segment s,
+// whose partials lane i of segment_sum_kernel's wave adds in that order.  A workgroup computes its jobs' sums with
+// the tile kernel's code, publishes each as two 8-byte {epoch, half} granules (write-through stores), and EVERY
+// workgroup gathers all jobs' granules, finishes the segment sums with the same DPP tree and runs chain_decide on its
+// own copy of the state: no second barrier, no broadcast, and the bits of the two-kernel path.  Granules alternate
+// between two buffers by iteration parity: a workgroup can only publish iteration e+2 after every workgroup has
+// published e+1, i.e. has finished reading e.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+struct PersistJob {
+  int64_t first_tile; // local tile index of the job's first tile (then +64 per further tile)
+  int32_t ntiles;
+  int32_t pub_idx;    // segment * 64 + lane: where the job's sum sits in the segment-sum wave
+};
+
+struct PersistArgs {
+  const void *X;
+  TileGeom g;
+  const int32_t *tile_valid;
+  const PersistJob *jobs;
+  int njobs, nseg;
+  unsigned long long *pub; // [2][2 * njobs] granules, zero before the launch
+  unsigned int *abort_word; // zero before the launch; non-zero: some workgroup gave up waiting
+  unsigned long long timeout_ticks; // of the 100 MHz wall clock
+};
+
+constexpr int kPersistMaxSeg = 16;
+constexpr int kPersistMaxJobs = kPersistMaxSeg * kWave;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void chain_persist_kernel(ChainDev c, PersistArgs a)
+{
+  __shared__ double red[kBlock / kWave];
+  __shared__ double vals[kPersistMaxJobs]; // [segment][lane] lane sums, 0.0 where a lane has no tiles
+  __shared__ int pubidx[kPersistMaxJobs];
+  __shared__ double slots[kMaxSegmentsDev];
+  __shared__ double terms[kPriorChunk];
+  __shared__ int s_accept, s_failed;
+  __shared__ ChainHdr hdr;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // cur[d], prop[d]
+  T *cur = (T *)smem, *prop = cur + ((c.d + 1) & ~1);
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int d = c.d, njobs = a.njobs;
+  const bool out = blockIdx.x == 0;
+  for (int k = tid; k < kPersistMaxJobs; k += kBlock) vals[k] = 0.0;
+  for (int q = tid; q < njobs; q += kBlock) pubidx[q] = a.jobs[q].pub_idx;
+  for (int k = tid; k < d; k += kBlock) {
+    cur[k] = ((const T *)c.cur)[k];
+    prop[k] = ((const T *)c.prop)[k];
+  }
+  if (tid == 0) {
+    hdr = *c.hdr;
+    s_failed = 0;
+  }
+  __syncthreads();
+  const T *X = (const T *)a.X;
+  ThetaArg<T> no_karg; // never read: theta is the proposal in LDS
+  uint32_t *vals32 = (uint32_t *)vals;
+
+  for (int it = 0; it < c.n; it++) {
+    const unsigned epoch = (unsigned)it + 1u;
+    gu64 *pb = (gu64 *)a.pub + (size_t)(it & 1) * 2 * (size_t)njobs;
+    // ---- this workgroup's jobs
+    for (int q = blockIdx.x; q < njobs; q += gridDim.x) {
+      const PersistJob job = a.jobs[q];
+      double v = 0.0;
+      for (int k = 0; k < job.ntiles; k++) {
+        const int64_t tile = job.first_tile + (int64_t)k * kWave;
+        double s = tile_lane_sum<T, 1, 16, false, false, false>(X + tile * a.g.tile_stride, a.g.col_stride, d,
+                                                                a.tile_valid[tile], no_karg, prop, nullptr);
+        s = block_sum(s, red);
+        if (tid == 0) v += s;
+        __syncthreads(); // `red` is reused by the next tile
+      }
+      if (tid == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        __hip_atomic_store(pb + 2 * q, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pb + 2 * q + 1, ((unsigned long long)epoch << 32) | (bits >> 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- gather every job's granules (each thread polls its own; the data is the flag)
+    bool failed = false;
+    for (int g = tid; g < 2 * njobs; g += kBlock) {
+      unsigned long long x;
+      unsigned long long t0 = 0;
+      for (unsigned spins = 0;; spins++) {
+        x = __hip_atomic_load(pb + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 255u) { // every wave reaches an exit: a bounded wait, and a word that tells the others
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          if (now - t0 > a.timeout_ticks ||
+              __hip_atomic_load((gu32 *)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            failed = true;
+            break;
+          }
+        }
+      }
+      vals32[2 * pubidx[g >> 1] + (g & 1)] = (uint32_t)x;
+    }
+    if (failed) {
+      __hip_atomic_store((gu32 *)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_failed = 1;
+    }
+    __syncthreads();
+    if (s_failed) break;
+    // ---- the segment sums' DPP tree over the 64 lane sums of each segment, then the decision
+    for (int s = wave; s < a.nseg; s += kBlock / kWave) {
+      const double v = wave_sum_lane63(vals[s * kWave + lane]);
+      if (lane == kWave - 1) slots[s] = v;
+    }
+    chain_decide<T>(c, it, 0, slots, a.nseg, terms, &s_accept, &hdr, cur, prop, out);
+    __syncthreads();
+  }
+  if (out) { // the state after the batch: to the chain's buffers and to the head of the download image
+    for (int k = tid; k < d; k += kBlock) {
+      ((T *)c.cur)[k] = cur[k];
+      if (c.cur_out) ((T *)c.cur_out)[k] = cur[k];
+    }
+    if (tid == 0) {
+      hdr.pad[0] = s_failed | (int)__hip_atomic_load((gu32 *)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *c.hdr = hdr;
+      if (c.hdr_out) *c.hdr_out = hdr;
+    }
+  }
 }
 
 } // namespace mhlik

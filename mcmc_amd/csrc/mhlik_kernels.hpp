@@ -163,22 +163,17 @@ __device__ __forceinline__ void tile_columns(const T *__restrict__ tbase, int64_
   }
 }
 
+// One tile's contribution: the row dots of the tile's rows against theta (columns in increasing order), then
+// -log(1+exp(.)) of the valid rows summed per lane in (r, k) order.  The caller adds the lanes with block_sum.
+// `theta_g` may point to global memory or LDS (KARG == false); KARG: theta from the kernarg struct.
 template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
-__global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ X, TileGeom g,
-                                                          const int32_t *__restrict__ tile_valid,
-                                                          ThetaArg<T> theta_k, const T *__restrict__ theta_g,
-                                                          double *__restrict__ partials,
-                                                          T *__restrict__ rowdots)
+__device__ __forceinline__ double tile_lane_sum(const T *__restrict__ tbase, int64_t col_stride, int d, int valid,
+                                                const ThetaArg<T> &theta_k, const T *__restrict__ theta_g,
+                                                T *__restrict__ rowdots_tile)
 {
   constexpr int VEC = Vec16<T>::N;
   constexpr int STEP = kBlock * VEC; // rows covered by one load of the whole workgroup
-  __shared__ double lds[kBlock / kWave];
-
-  const int64_t tile = blockIdx.x;
-  const int valid = tile_valid[tile];
-  const T *tbase = X + tile * g.tile_stride;   // wave-uniform
   const uint32_t lane_row = threadIdx.x * VEC; // first of this lane's VEC rows in group 0
-  const int d = g.d;
 
   T acc[R][VEC];
 #pragma unroll
@@ -187,18 +182,18 @@ __global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ 
     for (int k = 0; k < VEC; k++) acc[r][k] = (T)0;
 
   int j0 = 0;
-  for (; j0 + U <= d; j0 += U) tile_columns<T, R, U, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc);
+  for (; j0 + U <= d; j0 += U) tile_columns<T, R, U, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc);
   // d % U leftover columns: halve the batch until nothing is left
   if constexpr (U >= 32)
-    if (j0 + 16 <= d) { tile_columns<T, R, 16, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 16; }
+    if (j0 + 16 <= d) { tile_columns<T, R, 16, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 16; }
   if constexpr (U >= 16)
-    if (j0 + 8 <= d) { tile_columns<T, R, 8, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 8; }
+    if (j0 + 8 <= d) { tile_columns<T, R, 8, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 8; }
   if constexpr (U >= 8)
-    if (j0 + 4 <= d) { tile_columns<T, R, 4, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 4; }
+    if (j0 + 4 <= d) { tile_columns<T, R, 4, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 4; }
   if constexpr (U >= 4)
-    if (j0 + 2 <= d) { tile_columns<T, R, 2, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 2; }
+    if (j0 + 2 <= d) { tile_columns<T, R, 2, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 2; }
   if constexpr (U >= 2)
-    if (j0 + 1 <= d) { tile_columns<T, R, 1, NT, KARG>(tbase, g.col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 1; }
+    if (j0 + 1 <= d) { tile_columns<T, R, 1, NT, KARG>(tbase, col_stride, lane_row, j0, theta_k, theta_g, acc); j0 += 1; }
 
   double s = 0.0;
 #pragma unroll
@@ -208,11 +203,29 @@ __global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ 
       const int row = (int)lane_row + r * STEP + k;
       if (row < valid) {
         s += (double)neg_log1pexp(acc[r][k]);
-        if constexpr (ROWDOTS) rowdots[tile * (int64_t)(STEP * R) + row] = acc[r][k];
+        if constexpr (ROWDOTS) rowdots_tile[row] = acc[r][k];
       }
     }
   }
+  return s;
+}
 
+template <typename T, int R, int U, bool NT, bool KARG, bool ROWDOTS>
+__global__ __launch_bounds__(kBlock) void lik_tile_kernel(const T *__restrict__ X, TileGeom g,
+                                                          const int32_t *__restrict__ tile_valid,
+                                                          ThetaArg<T> theta_k, const T *__restrict__ theta_g,
+                                                          double *__restrict__ partials,
+                                                          T *__restrict__ rowdots)
+{
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int STEP = kBlock * VEC;
+  __shared__ double lds[kBlock / kWave];
+
+  const int64_t tile = blockIdx.x;
+  const int valid = tile_valid[tile];
+  const T *tbase = X + tile * g.tile_stride;   // wave-uniform
+  double s = tile_lane_sum<T, R, U, NT, KARG, ROWDOTS>(tbase, g.col_stride, g.d, valid, theta_k, theta_g,
+                                                       ROWDOTS ? rowdots + tile * (int64_t)(STEP * R) : nullptr);
   s = block_sum(s, lds);
   if (threadIdx.x == 0) partials[tile] = s;
 }

@@ -66,13 +66,15 @@ double log_prior(double *sample, mcmc_str mcin) { return log_prior_gpu(sample, m
  * is (the caller then owns the question of what is in it); without one the
  * matrix behind data.data is uploaded on EVERY call -- never taken from a
  * previous call, so a stale matrix cannot be evaluated -- into device buffers
- * that are kept between calls of the same shape and released at exit.  The
+ * that are kept between calls of the same shape until mcmc_amd_release_cached()
+ * (or left to the OS at exit: nothing is torn down from an exit handler, where
+ * the HIP runtime's own teardown order would decide whether that is safe).  The
  * upload runs at PCIe speed (0.17 s for 5.12 GB), still faster than one CPU
  * evaluation of the reference at that size. */
 static mhlik_ctx *g_ll_ctx = NULL;
-static int g_ll_n = 0, g_ll_d = 0, g_ll_atexit = 0;
+static int g_ll_n = 0, g_ll_d = 0;
 
-static void ll_release(void)
+void mcmc_amd_release_cached(void)
 {
   if (g_ll_ctx) mhlik_destroy(g_ll_ctx);
   g_ll_ctx = NULL;
@@ -87,7 +89,7 @@ double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res
       (info.precision & MHLIK_F64)) {
     lik = att;
   } else {
-    if (g_ll_ctx && (g_ll_n != mcin.Nd || g_ll_d != mcin.ddata)) ll_release();
+    if (g_ll_ctx && (g_ll_n != mcin.Nd || g_ll_d != mcin.ddata)) mcmc_amd_release_cached();
     if (!g_ll_ctx) {
       int owned = 0;
       mcmc_amd_attach_context(NULL);
@@ -95,10 +97,6 @@ double log_likelihood(double *sample, data_str data, mcmc_str mcin, out_str *res
       mcmc_amd_attach_context(att);
       g_ll_n = mcin.Nd;
       g_ll_d = mcin.ddata;
-      if (!g_ll_atexit) {
-        atexit(ll_release);
-        g_ll_atexit = 1;
-      }
     } else {
       if (!data.data) {
         fprintf(stderr, "ERROR: data.data is NULL and no context is attached.\n");

@@ -203,10 +203,13 @@ def test_chain_submit_collect_pipeline_equals_run(dtype):
         assert o["samples"] is None and len(o["lik"]) == 5
 
 
-def test_run_after_burn_in_allocates_nothing():
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_run_after_burn_in_allocates_nothing(monkeypatch, persist):
     """The driver's shape: a 4-iteration burn-in, then 20 timed iterations.  The second call must find every buffer
     in place: free device memory does not move, and neither does it over a longer run that fits the slots."""
     import torch
+
+    monkeypatch.setenv("MHLIK_CHAIN_PERSIST", persist)
 
     from mcmc_amd import Likelihood
 
@@ -221,6 +224,46 @@ def test_run_after_burn_in_allocates_nothing():
         free0 = torch.cuda.mem_get_info(0)[0]
         lk.chain_resume(np.zeros(d), -1e4, 10.0)
         a = lk.chain_run(inc[:20], logu[:20])
-        assert a["kernel_samples"] == 5  # every fourth launch of a short batch is bracketed with events (every eighth of a long one)
-        lk.chain_run(inc, logu)
+        # two-kernel path: every fourth launch of a short batch is bracketed with events (every eighth of a long one);
+        # persistent launch: one pair around the batch, counted as its 20 passes
+        assert a["kernel_samples"] == (5 if persist == "0" else 20)
         assert torch.cuda.mem_get_info(0)[0] == free0
+        # a longer run that fits the slots: the library allocates nothing either; the HIP runtime may grow its own
+        # kernel-argument pool once (512 launches with 2 KB of kernarg each; seen: one 2 MiB chunk)
+        lk.chain_run(inc, logu)
+        assert free0 - torch.cuda.mem_get_info(0)[0] <= 8 << 20
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,d,segments", [(10000, 3, 8), (1000, 1, 8), (40000, 16, 8), (300_000, 7, 8), (70_001, 33, 16),
+                                          (513, 5, 1), (3_000_000, 4, 8)])
+def test_persistent_chain_kernel_equals_two_kernel_path(monkeypatch, N, d, segments, dtype):
+    """chain_persist_kernel (the whole batch in one launch: every workgroup gathers every job's lane sum and decides
+    for itself) against the two-kernel-per-iteration path: every output bit for bit, over several batches, ragged tiles,
+    lanes with one tile and lanes with many, one segment and sixteen."""
+    from mcmc_amd import Likelihood
+
+    rng = np.random.default_rng(N + d)
+    n = 150
+    inc = rng.normal(0, 0.02, (n, d)).astype(dtype)
+    logu = np.log(rng.uniform(size=n)).astype(dtype)
+
+    def run(persist):
+        monkeypatch.setenv("MHLIK_CHAIN_PERSIST", persist)
+        with Likelihood(N, d, precision=3, segments=segments, timing=True) as lk:
+            lk.fill_synthetic(11)
+            cp = lk.chain_begin(np.full(d, 0.01, dtype=dtype), 10.0, dtype=dtype)
+            outs = [lk.chain_run(inc[:100], logu[:100], dtype=dtype), lk.chain_run(inc[100:101], logu[100:101], dtype=dtype),
+                    lk.chain_run(inc[101:], logu[101:], dtype=dtype)]
+            return cp, outs, lk.chain_state(dtype=dtype), lk.last_kernel_name()
+
+    cp0, a, st0, name0 = run("0")
+    cp1, b, st1, name1 = run("1")
+    assert name0.startswith("lik_tile_kernel") and name1.startswith("chain_persist_kernel")
+    assert cp0 == cp1
+    for x, y in zip(a, b):
+        for k in ("samples", "lik", "ratio", "accepted"):
+            assert np.array_equal(x[k], y[k]), k
+        assert x["n_accepted"] == y["n_accepted"] and y["kernel_ms"] > 0
+    assert 0 < sum(x["n_accepted"] for x in a) < n
+    assert np.array_equal(st0[0], st1[0]) and st0[1] == st1[1]
