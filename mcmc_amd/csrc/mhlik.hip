@@ -127,6 +127,7 @@ struct Store {
   SegDesc *segs = nullptr;                 // device [nseg_local]
   PersistJob *pjobs = nullptr;             // device [npjobs]: the (segment, lane) jobs of the persistent chain kernel
   int npjobs = 0;
+  std::vector<PersistJob> h_pjobs;
   std::vector<int32_t> h_valid;
   std::vector<int64_t> h_row0;
   std::vector<SegDesc> h_segs;
@@ -165,7 +166,6 @@ struct ChainHost {
   ChainHdr host_hdr;
   std::vector<unsigned char> host_cur;
   unsigned char *persist_words = nullptr; // device: [abort word, 16 B][2][2 * kPersistMaxJobs] granules
-  int persist_blocks_per_cu[2] = {0, 0};  // occupancy of chain_persist_kernel<double / float>, looked up once
 };
 
 // K lock-step chains on the device (mhlik_kchain.hpp): states + one batch of buffers.
@@ -389,6 +389,7 @@ template <typename T> int build_store(mhlik_ctx *c)
     HIPCHK(c, hipMalloc((void **)&s.pjobs, sizeof(PersistJob) * jobs.size()));
     HIPCHK(c, hipMemcpy(s.pjobs, jobs.data(), sizeof(PersistJob) * jobs.size(), hipMemcpyHostToDevice));
     s.npjobs = (int)jobs.size();
+    s.h_pjobs = jobs;
   }
   c->hbm_bytes += s.bytes;
 

@@ -236,11 +236,12 @@ def test_run_after_burn_in_allocates_nothing(monkeypatch, persist):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("N,d,segments", [(10000, 3, 8), (1000, 1, 8), (40000, 16, 8), (300_000, 7, 8), (70_001, 33, 16),
-                                          (513, 5, 1), (3_000_000, 4, 8)])
+                                          (513, 5, 1), (3_000_000, 4, 8), (1_000_000, 16, 8), (2_000_003, 9, 4)])
 def test_persistent_chain_kernel_equals_two_kernel_path(monkeypatch, N, d, segments, dtype):
     """chain_persist_kernel (the whole batch in one launch: every workgroup gathers every job's lane sum and decides
     for itself) against the two-kernel-per-iteration path: every output bit for bit, over several batches, ragged tiles,
-    lanes with one tile and lanes with many, one segment and sixteen."""
+    lanes with one tile and lanes with many, one segment and sixteen; tiles held in registers (d <= 16), in LDS and
+    re-read from memory (3M x 4: 8 + 8 + 7 per workgroup; 1M x 16: 5 + 2 + 1), and d = 33 with nothing resident."""
     from mcmc_amd import Likelihood
 
     rng = np.random.default_rng(N + d)
