@@ -78,7 +78,8 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert two["n_gpus"] == 2 and two["config"]["rows_per_gpu"] == 200000
     assert "fallback host loop" in two["config"]["parallelism"] and two["rccl_ranks"] == 0
     assert two["acceptance"] == one["acceptance"]
-    assert one["rccl_ranks"] == 0 and one["roofline"]["kernel"] == "lik_tile_kernel<double, 1, 16, true, false, false>"
+    # 400k x 16 fits the workgroups' registers: the single-process run is the persistent chain kernel
+    assert one["rccl_ranks"] == 0 and one["roofline"]["kernel"] == "chain_persist_kernel<double, 16, 5>"
     big = two["extra"]["n100m"]
     assert "error" not in big and big["rows_per_gpu"] == 600000 and big["in_library_rccl"] is False
 
