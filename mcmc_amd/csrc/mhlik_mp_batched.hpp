@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__r
     }
     __syncthreads();
   };
-  batched_x3_stream<NB, 6, 0>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave, g.col_stride, g.d,
+  batched_x3_stream<NB, 6>(X, g.tile_stride, (int64_t)blockIdx.x, (int64_t)gridDim.x, ntiles, wave, g.col_stride, g.d,
                               d_pad, thetaL, lane, epi, tile_done);
 }
 

@@ -7,7 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
-#include "mhlik_batched_x3.hpp"
+#include "x3_lab_variants.hpp"
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -62,17 +62,17 @@ int main(int argc, char **argv)
   mhlik_x3_stage_theta(theta.data(), K, 1, d, K, d_pad, NB, img3.data());
   u32x4 *th3; CK(hipMalloc(&th3, img3.size() * 4)); CK(hipMemcpy(th3, img3.data(), img3.size() * 4, hipMemcpyHostToDevice));
 
-#define RUN(EXPV, label) { auto k = lik_batched_x3_kernel<4, 6, EXPV>; \
+#define RUN(EXPV, label) { auto k = lab_lik_batched_x3_kernel<4, 6, EXPV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 512 ? ntiles : 512), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
   size_t lds3 = img3.size() * 4 + sizeof(double) * 4 * 4 * 64;
   (void)flops; (void)th32;
-#define RUNN(NBUFV, label) { auto k = lik_batched_x3_kernel<4, 6, 0, NBUFV>; \
+#define RUNN(NBUFV, label) { auto k = lab_lik_batched_x3_kernel<4, 6, 0, NBUFV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
-#define RUNNL(NBUFV, label) { auto k = lik_batched_x3_kernel<4, 6, 5, NBUFV>; \
+#define RUNNL(NBUFV, label) { auto k = lab_lik_batched_x3_kernel<4, 6, 5, NBUFV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); printf("%-46s %.3f ms  %6.0f GB/s\n", label, ms, (double)N * d * 4 / ms / 1e6); }
@@ -80,6 +80,8 @@ int main(int argc, char **argv)
     RUNN(4, "one wave per SIMD, four load buffers")
     RUNNL(4, "one wave per SIMD, four buffers, loads only")
     RUN(0, "production")
+    RUN(8, "production, 1 KB-contiguous wave loads")
+    RUN(13, "loads only, 1 KB-contiguous wave loads")
     RUN(256, "production + workgroup barrier per k-block")
     RUN(128, "exp + log per element (the round-1 epilogue)")
     RUN(512, "packed-subtraction split (v_pk_add_f32)")

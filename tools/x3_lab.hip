@@ -7,7 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
-#include "mhlik_batched_x3.hpp"
+#include "x3_lab_variants.hpp"
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds32, 0, X, g, tv, th32, d, P, (int64_t)ntiles, K); }, reps); \
     CK(hipDeviceSynchronize()); report(label, ms, (EXPV) & 1); }
 #define RUNX3(TERMSV, EXPV, label) RUNX3D(TERMSV, EXPV, 0, label)
-#define RUNX3D(TERMSV, EXPV, DBV, label) { auto k = lik_batched_x3_kernel<4, TERMSV, EXPV>; \
+#define RUNX3D(TERMSV, EXPV, DBV, label) { auto k = lab_lik_batched_x3_kernel<4, TERMSV, EXPV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 512 ? ntiles : 512), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); report(label, ms, (EXPV) & 1); }
@@ -113,7 +113,7 @@ int main(int argc, char **argv)
   RUNX3(6, 3, "x3 6 terms, no loads, plain sum")
   RUNX3(6, 5, "x3 loads only, plain sum")
   RUNX3(6, 0, "x3 6 terms (again)")
-#define RUNX3B(label) { auto k = lik_batched_x3_kernel<4, 6, 0, 3>; \
+#define RUNX3B(label) { auto k = lab_lik_batched_x3_kernel<4, 6, 0, 3>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles < 512 ? ntiles : 512), dim3(256), lds3, 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, K, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); report(label, ms, false); }
@@ -122,12 +122,12 @@ int main(int argc, char **argv)
   RUNX3(6, 0, "x3 6 terms (plain again)")
   RUNX3(6, 16, "x3 6 terms, split under the MFMAs")
   // occupancy experiments: loads only, one chain block (few registers), 2 / 4 / 8 workgroups per CU
-#define RUNOCC(PERCU, label) { auto k = lik_batched_x3_kernel<1, 6, 5>; \
+#define RUNOCC(PERCU, label) { auto k = lab_lik_batched_x3_kernel<1, 6, 5>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     const long gr = ntiles < 256 * PERCU ? ntiles : 256 * PERCU; \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(gr), dim3(256), (size_t)(lds3 / 4 + 4096), 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, 16, (int64_t)ntiles); }, reps); \
     CK(hipDeviceSynchronize()); report(label, ms, true); }
-#define RUNPAT(EXPV, GRID, label) { auto k = lik_batched_x3_kernel<1, 6, EXPV>; \
+#define RUNPAT(EXPV, GRID, label) { auto k = lab_lik_batched_x3_kernel<1, 6, EXPV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
     const long gr = (GRID); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(gr), dim3(256), (size_t)(lds3 / 4 + 4096), 0, X, g, tv, th3, d_pad, P, (int64_t)ntiles, 16, (int64_t)ntiles); }, reps); \
