@@ -540,7 +540,7 @@ def workload_name(N, d):
             (100_000_000, 64): "BASELINE configs[3]"}.get((N, d), "custom size")
 
 
-TRAFFIC_PROFILE = "profiles/r02_bench_pmc_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_bench_pmc_hbm_traffic.json"
 
 
 def pmc_traffic(N, d, local_rows, kernel_name):

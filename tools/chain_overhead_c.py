@@ -17,7 +17,7 @@ def main():
     with Likelihood(N, d, precision=F64, timing=True) as lk:
         lk.fill_synthetic(12345)
         rwsd = 2.38 / np.sqrt(d) * 2e-3
-        for K in (1, 20, 20, 100):
+        for K in (20, 100, 300, 300):
             samples = np.zeros((K, d)); burn = np.zeros((5, d))
             mcin = S.mcmc_str(ddata=d, Nd=N, Ns=K, burnin=5, impl=S.IMPL_GPU)
             mct = S.mcmc_tune_str(rwsd=rwsd, rwsdf=rwsd)
@@ -28,7 +28,7 @@ def main():
             rng = S.Rng(0)
             lib.burn_in_metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc))
             el = []
-            for rep in range(8):
+            for rep in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 lib.metropolis_gpu(lk.handle, rng.r, mcin, mct, mcdata, mclocv, C.byref(mcloc), C.byref(accepted), C.byref(res))
