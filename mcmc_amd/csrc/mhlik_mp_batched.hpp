@@ -582,17 +582,11 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_kernel(const float *__re
 //                (tools/check_mfma_order.hip), which log(L - B) needs: it is the log of a one-float-ulp difference;
 //   double dots  v_mfma_f64_16x16x4_f64 -- a fused chain, so within 1 ulp of the unfused mul+add chain of the
 //                single-chain kernel, not the same bits; it enters through L = 1/(1+e^x) only.
-// Work item = one 64-row segment of a block x one group of 16 chains, one wave.  A operand: lane (i = l&15,
-// g = l>>4) loads column j0+g; float: rows 4i..4i+3 (16 bytes, row set m = row 4i+m); double: rows 4s..4s+3 with
-// s = 4*(i&3) + (i>>2) (32 bytes).  The two MFMAs lay their results out differently (float: A-row 4g+r, double:
-// A-row g+4r in lane (c, g), register r); with that permutation of the double rows element (m, r) of both is
-// row 4*(4g+r)+m of the segment, chain 16*group + c.  Theta sits in LDS transposed ([column][64 chains]) so that
-// a B operand is one conflict-free read.  Per (row, chain) the same mpb_pair_terms as above; sums over a lane's 16
-// elements, then over the four lane groups, then over the block's segments, in that fixed order.
-// A workgroup (16 waves) owns the same contiguous run of blocks as in mpb_fix_kernel.  Wave w serves chain group
-// w & 3 and every fourth block worth a visit (w >> 2 picks which): it walks the block's segments, adds up its 16
-// chains' terms and resamples those 16 indicators itself, so no wave waits for another (no barriers, no result
-// tables in LDS) and the waves of a SIMD drift apart, one's epilogue under another's MFMAs.
+// The two MFMAs lay their results out differently (float: A-row 4g+r, double: A-row g+4r in lane (c, g),
+// register r); the double rows are loaded in the permutation that makes element r of both the same row.
+// Per (row, chain) the same mpb_pair_terms as above.
+// Rounds 1-2 gave a wave 64 rows x 16 chains (16-byte loads, four row sets): the four waves of a block then
+// streamed the same rows (HBM traffic 1.34 x the algorithmic bytes) with two k-steps of twelve registers in flight.
 __device__ __forceinline__ double lanes_xor_sum_16_32(double v) // lanes c, c+16, c+32, c+48 -> (g0+g1)+(g2+g3)
 {
   v += __shfl_xor(v, 16);
@@ -600,57 +594,79 @@ __device__ __forceinline__ double lanes_xor_sum_16_32(double v) // lanes c, c+16
   return v;
 }
 
-__global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float *__restrict__ Xf, TileGeom gf,
-                                                                     const double *__restrict__ Xd, TileGeom gd,
-                                                                     const double *__restrict__ Theta,
-                                                                     const float *__restrict__ Thetaf, int d_pad,
-                                                                     MpbParams p, const MpbChainArgs *__restrict__ ca,
-                                                                     const MpbSeg *__restrict__ segtab,
-                                                                     int8_t *__restrict__ z, double *__restrict__ acc_out,
-                                                                     int32_t *__restrict__ cnt_out)
+
+// The dense correction with every row read ONCE: one wave dots 16 rows against all 64 chains.
+// A lane (c = l&15, g = l>>4) loads one float and one double per k-step -- row c (float) / row 4(c&3) + (c>>2)
+// (double, the permutation that lines the two MFMAs' results up) of its 16-row quarter of a 64-row
+// segment, column 4k + g -- and runs four v_mfma_f32_16x16x4_f32 and four v_mfma_f64_16x16x4_f64 on it, one per
+// 16-chain group n: accumulator element (n, r) of lane (c, g) is row 4g + r, chain 16n + c.  A k-step costs 3
+// registers per lane, so D of them are in flight per wave where the 64-row x 16-chain shape had two of twelve
+// registers each, and the four waves that used to stream the same rows now stream four different quarters:
+// nothing is requested twice.  An address is a wave-uniform base (segment, k-step) plus one 32-bit lane offset.
+// Theta sits in LDS as doubles only, [column][chain pair n>>1][c][n&1] (a lane's four B operands are two
+// conflict-free 16-byte reads); the float operand is (float) of the double, which is how mpb_theta_prep_kernel
+// makes the float Theta of the other kernels.
+// A workgroup (NT threads, NT/256 "stripes" of four waves) owns the same run of blocks as before and compacts the
+// blocks worth a visit the same way.  The visited blocks are taken round_blocks (<= 16) at a time; the round's
+// 64-row segments, numbered block by block, are dealt to the stripes in turn, and wave (stripe q = w>>2,
+// sub = w&3) streams rows 16 sub .. 16 sub + 15 of every segment of stripe q (one load pipeline across segments
+// and blocks; a 1024-row block is four stripes' work, four 64-row blocks are one each), adds per chain the sums
+// over those rows into res[block of round][stripe slot][sub][chain] (slot = segment mod the slots per block,
+// min(segments per block, stripes): an entry has one writer), and after a barrier thread (block of round, chain)
+// adds the block's entries in order, resamples the indicator and keeps the chain's running bright sum and count:
+// the outputs have the layout mpb_fix_kernel writes ([16 rows per workgroup][64]).
+// Order of every sum: a lane's four rows, the four lane groups (xor 16, xor 32), a slot's segments (seg, seg + 4,
+// ...), the slots, the four quarters of each -- fixed by block_rows alone.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int kMpbDenseRound = 16; // visited blocks per round at most (one row of the outputs each)
+constexpr int kMpbDenseDepth = 4;  // k-steps in flight per wave (8 spill at 16 waves per workgroup: profiles/r03_fix_dense_lab.txt)
+
+template <int NT, int D>
+__global__ __launch_bounds__(NT) void mpb_fix_dense_kernel(const float *__restrict__ Xf, TileGeom gf,
+                                                             const double *__restrict__ Xd, TileGeom gd,
+                                                             const double *__restrict__ Theta, int theta_ld, int d_pad,
+                                                             MpbParams p, const MpbChainArgs *__restrict__ ca,
+                                                             const MpbSeg *__restrict__ segtab, int8_t *__restrict__ z,
+                                                             double *__restrict__ acc_out, int32_t *__restrict__ cnt_out,
+                                                             int round_blocks)
 {
-  typedef Vec16<float>::type F4;
-  typedef Vec16<double>::type D2;
-  constexpr int NW = kMpbFixBlock / kWave;
+  constexpr int NW = NT / kWave, NQ = NW / 4;
+  constexpr int kOutRows = kMpbFixBlock / kWave; // rows of acc_out / cnt_out per workgroup
+  static_assert(NW % 4 == 0 && kMpbDenseRound <= kOutRows && kOutRows % NW == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *thdT = reinterpret_cast<double *>(smem);                                              // [d_pad][64]
-  float *thfT = reinterpret_cast<float *>(smem + sizeof(double) * (size_t)d_pad * kBatchCols);  // [d_pad][64]
-  for (int i = threadIdx.x; i < d_pad * kBatchCols; i += kMpbFixBlock) {
-    const int j = i >> 6, c = i & 63;
-    thdT[i] = c < p.K ? Theta[(size_t)c * d_pad + j] : 0.0;
-    thfT[i] = c < p.K ? Thetaf[(size_t)c * d_pad + j] : 0.f;
+  double *thd = reinterpret_cast<double *>(smem);                                               // [d_pad][2][16][2]
+  double *res = reinterpret_cast<double *>(smem + sizeof(double) * (size_t)d_pad * kBatchCols); // [round][spb][4][64][2]
+  // Theta: [K][theta_ld] in global memory (coalesced reads), zero beyond K chains / theta_ld columns
+  for (int i = threadIdx.x; i < d_pad * kBatchCols; i += NT) {
+    const int chain = i / d_pad, j = i - chain * d_pad;
+    const int n = chain >> 4, cc = chain & 15;
+    thd[((j * 2 + (n >> 1)) * 16 + cc) * 2 + (n & 1)] = (chain < p.K && j < theta_ld) ? Theta[(size_t)chain * theta_ld + j] : 0.0;
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wave_global = blockIdx.x * NW + wave;
-  const int ai = lane & 15, ag = lane >> 4;
-  const int arow_f = 4 * ai, arow_d = 4 * (4 * (ai & 3) + (ai >> 2));
+  const int c = lane & 15, g = lane >> 4;
+  const int sub = wave & 3, stripe = wave >> 2;
   const int d = gf.d;
-  const int csf = (int)gf.col_stride, csd = (int)gd.col_stride;
+  const int nk = d_pad >> 2; // a multiple of D; k-steps past the last column meet zeros in Theta
+  const int row_f = 16 * sub + c, row_d = 16 * sub + 4 * (c & 3) + (c >> 2);
+  const int csf = (int)gf.col_stride, csd = (int)gd.col_stride; // offsets inside one tile fit 32 bits
   const int64_t all = (int64_t)p.blocks << p.block_shift;
   const int64_t covered = all < p.n_rows ? all : p.n_rows;
-  const int grp = wave & 3, quarter = wave >> 2;
-  const int chain = 16 * grp + ai; // the four lane groups hold replicas of everything that is per chain
-  const bool chain_live = chain < p.K;
-  const int my_choose = ca->choose[chain];
-  const uint64_t my_seed = ca->seed[chain];
-  const float *bf = thfT + chain;
-  const double *bd = thdT + chain;
+  const int segs = p.block_rows >> 6, seg_shift = p.block_shift - 6; // a power of two
+  const int spb = segs < NQ ? segs : NQ; // table slots per block: one per stripe that works on it
+  const int my_choose = ca->choose[lane];
+  const uint64_t my_seed = ca->seed[lane];
   double acc_b = 0.0;
   int32_t cnt = 0;
 
-  const int segs = p.block_rows >> 6;
   const MpbSeg sg = segtab[blockIdx.x / p.seg_groups]; // as in mpb_fix_kernel
   const int64_t chunk = ((int64_t)(sg.blk_hi - sg.blk_lo) + p.seg_groups - 1) / p.seg_groups;
   const int64_t wg_begin = sg.blk_lo + (int64_t)(blockIdx.x % p.seg_groups) * chunk;
   const int64_t wg_end = wg_begin + chunk < sg.blk_hi ? wg_begin + chunk : sg.blk_hi;
 
-  // Blocks worth a visit, in index order: on the shared phase, or bright for some chain (a bright block without
-  // rows is visited only to be counted).  With 1/F of the blocks on the phase most are not, so the run is
-  // compacted first, 1024 blocks (one per thread) at a time.
-  __shared__ int visit_list[kMpbFixBlock];
+  __shared__ int visit_list[NT];
   __shared__ int visit_count[NW];
   const int choose0 = ca->choose[0];
-  for (int64_t base = wg_begin; base < wg_end; base += kMpbFixBlock) { // workgroup-uniform trip count
+  for (int64_t base = wg_begin; base < wg_end; base += NT) { // workgroup-uniform trip count
     {
       const int64_t b = base + threadIdx.x;
       bool visit = false;
@@ -676,101 +692,186 @@ __global__ __launch_bounds__(kMpbFixBlock) void mpb_fix_dense_kernel(const float
     for (int w = 0; w < NW; w++) n_visit += visit_count[w];
     __syncthreads();
 
-    for (int q = quarter; q < n_visit; q += NW / 4) { // this wave's blocks; no barrier in here
-      const int64_t b = base + visit_list[q];
-      int8_t zc = chain_live ? z[b * kBatchCols + chain] : (int8_t)0;
-      const bool has_rows = (b << p.block_shift) < p.n_rows;
-      const bool bright = zc != 0;
-      const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
-      const bool need = chain_live && has_rows && (bright || re);
-      if (__ballot(need) != 0) { // wave-uniform: some chain of this group needs the block
-        double rs_tot = 0.0, lb_tot = 0.0;
-        for (int seg = 0; seg < segs; seg++) {
-          const int64_t first = (b << p.block_shift) + (int64_t)seg * 64;
-          if (first >= covered) break; // wave-uniform
-          const int64_t lfirst = first - p.row_base; // row of this context's store
-          const float *pf = Xf + (lfirst >> 10) * gf.tile_stride + (lfirst & 1023) + arow_f;
-          const double *pd = Xd + (lfirst >> 9) * gd.tile_stride + (lfirst & 511) + arow_d;
-          f32x4 af[4];
-          f64x4 ad[4];
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            af[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ad[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int r0 = 0; r0 < n_visit; r0 += round_blocks) { // workgroup-uniform trip count
+      const int rc = n_visit - r0 < round_blocks ? n_visit - r0 : round_blocks;
+      // ---- stream: the round's 64-row segments are dealt to the stripes in order; this wave's quarter of its
+      // stripe's segments ----------------------------------------------------------------------------------
+      const int units = rc << seg_shift;
+      auto slot_segs = [&](int64_t b) -> int { // 64-row segments of block b that hold rows
+        const int64_t left = covered - (b << p.block_shift);
+        if (left <= 0) return 0;
+        const int64_t s = (left + 63) >> 6;
+        return s < segs ? (int)s : segs;
+      };
+      struct Pos { // a quarter-segment ("unit") of this wave's stream and a k-step in it; all wave-uniform
+        int u, k, r, seg; // unit = (block of the round r, segment seg), u = r * segs + seg
+        int64_t b;
+        const float *pf;  // the segment's row 0, column 0
+        const double *pd;
+      };
+      auto seek = [&](Pos &q) -> bool { // first unit of this stripe at or after q.u whose segment holds rows
+        for (; q.u < units; q.u += NQ) {
+          q.r = q.u >> seg_shift;
+          q.seg = q.u & (segs - 1);
+          q.b = base + visit_list[r0 + q.r];
+          if (q.seg < slot_segs(q.b)) {
+            const int64_t lfirst = (q.b << p.block_shift) + (int64_t)q.seg * 64 - p.row_base;
+            q.pf = Xf + (lfirst >> 10) * gf.tile_stride + (lfirst & 1023);
+            q.pd = Xd + (lfirst >> 9) * gd.tile_stride + (lfirst & 511);
+            return true;
           }
-          // column of this lane in k-step j0: j0 + g, clamped to the last real column (its Theta entry is zero)
-          auto col = [&](int j0) { const int j = j0 + ag; return j < d ? j : d - 1; };
-          // two k-steps of rows in flight: buffers A and B alternate, each reloaded right after the MFMAs that
-          // read it have been issued (no copies, so a load has two k-steps of MFMAs to land under)
-          auto loadk = [&](int j0, F4 &f, D2 &a0, D2 &a1) {
-            const int j = col(j0);
-            f = load16<float, false>(pf + (int64_t)j * csf);
-            a0 = load16<double, false>(pd + (int64_t)j * csd);
-            a1 = load16<double, false>(pd + (int64_t)j * csd + 2);
-          };
-          auto mfmak = [&](int j0, const F4 &f, const D2 &a0, const D2 &a1) {
-            const float tb = bf[(j0 + ag) * kBatchCols];
-            const double tdv = bd[(j0 + ag) * kBatchCols];
+        }
+        return false;
+      };
+      auto next_unit = [&](Pos &q) -> bool { // false (and q unchanged) after the wave's last unit
+        Pos n = q;
+        n.u += NQ;
+        if (!seek(n)) return false;
+        q = n;
+        return true;
+      };
+      struct Buf {
+        float f;
+        double x;
+      };
+      Buf ring[D];
+      auto load = [&](Buf &bf, const Pos &q) { // column 4k + g, or the last real column (Theta is zero there)
+        int j = 4 * q.k + g;
+        j = j < d ? j : d - 1;
+        bf.f = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(q.pf) +
+                                                (unsigned)((j * csf + row_f) * (int)sizeof(float)));
+        bf.x = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(q.pd) +
+                                                 (unsigned)((j * csd + row_d) * (int)sizeof(double)));
+      };
+      auto load_next = [&](Buf &bf, Pos &q) { // request the load position's k-step, then step it; past the end of
+        load(bf, q);                          // the stream it wraps inside the last unit (requests nobody reads)
+        if (++q.k == nk) {
+          q.k = 0;
+          (void)next_unit(q);
+        }
+      };
+      f32x4 af[4];
+      f64x4 ad[4];
+      Pos w{stripe, 0, 0, 0, 0, nullptr, nullptr};
+      if (seek(w)) {
+        Pos l = w;
 #pragma unroll
-            for (int m = 0; m < 4; m++) af[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[m], tb, af[m], 0, 0, 0);
-            ad[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], tdv, ad[0], 0, 0, 0);
-            ad[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], tdv, ad[1], 0, 0, 0);
-            ad[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], tdv, ad[2], 0, 0, 0);
-            ad[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], tdv, ad[3], 0, 0, 0);
-          };
-          const int nk = d_pad >> 2;
-          F4 fA, fB;
-          D2 a0A, a1A, a0B, a1B;
-          loadk(0, fA, a0A, a1A);
-          fB = fA, a0B = a0A, a1B = a1A;
-          if (nk > 1) loadk(4, fB, a0B, a1B);
-          int k = 0;
-          for (; k + 2 <= nk; k += 2) {
-            mfmak(4 * k, fA, a0A, a1A);
-            if (k + 2 < nk) loadk(4 * (k + 2), fA, a0A, a1A);
-            mfmak(4 * (k + 1), fB, a0B, a1B);
-            if (k + 3 < nk) loadk(4 * (k + 3), fB, a0B, a1B);
+        for (int b = 0; b < D; b++) load_next(ring[b], l);
+        bool more = true;
+        while (more) {
+          // which of this lane's four chains need block w.b, which are bright (read again per segment: cheap)
+          unsigned needm = 0, brightm = 0;
+#pragma unroll
+          for (int n = 0; n < 4; n++) {
+            const int chain = 16 * n + c;
+            const bool live = chain < p.K;
+            const int8_t zc = live ? z[w.b * kBatchCols + chain] : (int8_t)0;
+            const bool bright = zc != 0;
+            const bool re = !bright && live && ((int)(w.b % p.resamp_factor) == ca->choose[chain]);
+            if (live && (bright || re)) needm |= 1u << n;
+            if (bright) brightm |= 1u << n;
+            af[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ad[n] = f64x4{0.0, 0.0, 0.0, 0.0};
           }
-          if (k < nk) mfmak(4 * k, fA, a0A, a1A);
-          // element (m, r): segment row 4*(4g + r) + m, chain 16*grp + c
-          double s_rs = 0.0, s_lb = 0.0;
-          if (need) {
+          // chain groups none of whose 16 chains needs the block (a block visited for one bright chain) cost no MFMAs
+          unsigned groups = 0;
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+          for (int n = 0; n < 4; n++) groups |= __ballot((needm >> n) & 1u) != 0 ? 1u << n : 0u;
+          auto ksteps = [&](auto all_tag) {
+            constexpr bool kAll = decltype(all_tag)::value;
+            for (int kk = 0; kk < nk; kk += D) {
+#pragma unroll
+              for (int b = 0; b < D; b++) {
+                const double *tb = thd + (size_t)(4 * (kk + b) + g) * kBatchCols + c * 2;
+                const f64x2 t01 = *reinterpret_cast<const f64x2 *>(tb);
+                const f64x2 t23 = *reinterpret_cast<const f64x2 *>(tb + 32);
+                const double tn[4] = {t01[0], t01[1], t23[0], t23[1]};
+                const float xf = ring[b].f;
+                const double xd = ring[b].x;
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                  if (kAll || ((groups >> n) & 1u)) af[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf, (float)tn[n], af[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                  if (kAll || ((groups >> n) & 1u)) ad[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, tn[n], ad[n], 0, 0, 0);
+                load_next(ring[b], l);
+              }
+            }
+          };
+          if (groups == 0xfu)
+            ksteps(std::true_type{});
+          else
+            ksteps(std::false_type{});
+          // the quarter-segment is complete: its terms, per chain
+          const int64_t first = (w.b << p.block_shift) + (int64_t)w.seg * 64 + 16 * sub + 4 * g;
+          // the table entry of (block, stripe slot, sub): the block's segments seg, seg + NQ, ... add up in it
+          double *out = res + ((size_t)((w.r * spb + (w.seg & (spb - 1))) * 4 + sub) * kBatchCols) * 2;
+#pragma unroll
+          for (int n = 0; n < 4; n++) {
+            double s_rs = 0.0, s_lb = 0.0;
+            if ((needm >> n) & 1u) {
+              const bool bright = (brightm >> n) & 1u;
 #pragma unroll
               for (int r = 0; r < 4; r++) {
-                if (first + 4 * (4 * ag + r) + m < covered) {
+                if (first + r < covered) {
                   double rs_fast;
-                  if (!bright && mpb_reexamined_term(af[m][r], ad[m][r], p.eps, rs_fast)) {
+                  if (!bright && mpb_reexamined_term(af[n][r], ad[n][r], p.eps, rs_fast)) {
                     s_rs += rs_fast;
                   } else {
-                    const MpbTerms t = mpb_pair_terms(af[m][r], ad[m][r], p.eps, bright);
+                    const MpbTerms t = mpb_pair_terms(af[n][r], ad[n][r], p.eps, bright);
                     s_rs += t.rs;
                     if (bright) s_lb += t.lb;
                   }
                 }
               }
+            }
+            s_rs = lanes_xor_sum_16_32(s_rs);
+            s_lb = lanes_xor_sum_16_32(s_lb);
+            if (g == 0) { // the block's segments add up in res, in order (this wave alone touches the entry)
+              double *o = out + (16 * n + c) * 2;
+              o[0] = w.seg < spb ? s_rs : o[0] + s_rs;
+              o[1] = w.seg < spb ? s_lb : o[1] + s_lb;
+            }
           }
-          rs_tot += lanes_xor_sum_16_32(s_rs);
-          lb_tot += lanes_xor_sum_16_32(s_lb);
+          more = next_unit(w);
         }
-        if (need) {
+      }
+      __syncthreads();
+      // ---- resample: thread (block of the round, chain) ----------------------------------------------------
+      for (int slot = wave; slot < rc; slot += NW) {
+        const int64_t b = base + visit_list[r0 + slot];
+        int8_t zc = lane < p.K ? z[b * kBatchCols + lane] : (int8_t)0;
+        const bool has_rows = (b << p.block_shift) < p.n_rows; // a block without rows keeps its indicator
+        const bool bright = zc != 0;
+        const bool re = !bright && ((int)(b % p.resamp_factor) == my_choose);
+        const bool need = lane < p.K && has_rows && (bright || re);
+        if (need) { // the block's stripe slots that hold rows, four quarters each, in order
+          const int nsg = slot_segs(b);
+          const int parts = 4 * (nsg < spb ? nsg : spb);
+          const double *in = res + ((size_t)(slot * spb * 4) * kBatchCols + lane) * 2;
+          double rs_tot = in[0], lb_tot = in[1];
+          for (int s = 1; s < parts; s++) {
+            rs_tot += in[(size_t)s * kBatchCols * 2 + 0];
+            lb_tot += in[(size_t)s * kBatchCols * 2 + 1];
+          }
           const double u = mp_uniform(my_seed, p.u_call, (uint64_t)b);
           const double p_bright = 1.0 - exp(rs_tot);
           const int8_t zn = (p_bright <= u) ? 0 : 1; // mcmc_mp.cu:185-193
           if (bright) acc_b += lb_tot;
-          if (zn != zc && ag == 0) z[b * kBatchCols + chain] = zn;
+          if (zn != zc) z[b * kBatchCols + lane] = zn;
           zc = zn;
         }
+        cnt += zc != 0 ? 1 : 0;
       }
-      cnt += zc != 0 ? 1 : 0;
+      __syncthreads(); // the next round rewrites res (and the next window the list)
     }
-    __syncthreads(); // the next window rebuilds the list
   }
-  // row wave_global of the outputs: this wave's 16 chains, zeros elsewhere (lane l <-> chain l)
-  const bool mine = (lane >> 4) == grp;
-  acc_out[(int64_t)wave_global * kBatchCols + lane] = mine ? acc_b : 0.0;
-  cnt_out[(int64_t)wave_global * kBatchCols + lane] = mine ? cnt : 0;
+  // rows wave, wave + NW, ... of this workgroup's 16: a wave's running sums in the first, zeros in the others
+  for (int row = wave; row < kOutRows; row += NW) {
+    const int64_t o = ((int64_t)blockIdx.x * kOutRows + row) * kBatchCols + lane;
+    acc_out[o] = row == wave ? acc_b : 0.0;
+    cnt_out[o] = row == wave ? cnt : 0;
+  }
 }
 
 // grid = (K, local segments).  Per chain k and local segment: the dark pass's tile partials of the segment's tiles and
