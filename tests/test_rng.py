@@ -100,3 +100,87 @@ def test_ziggurat_tables_regenerate():
     assert out == open(os.path.join(root, "mcmc_amd", "csrc", "gslcompat", "zig_tables.h")).read()
     # spot values of GSL's tables (gauss ziggurat, J. Voss)
     assert "0.963598623011" in out and "12590644UL" in out and "1.62318314817e-08" in out and "2.22600839893e-07" in out
+
+
+def _numpy_mt(seed, n):
+    """n raw 32-bit outputs of MT19937 seeded with init_genrand(seed): numpy's legacy RandomState, an implementation
+    that shares nothing with gslcompat.c (gsl_rng_set(r, 0) means seed 4357)."""
+    rs = np.random.RandomState(seed if seed else 4357)
+    return rs.randint(0, 2**32, size=n, dtype=np.uint64).astype(np.uint64)
+
+
+def test_mt19937_stream_equals_numpys_for_several_seeds():
+    L = O.lib()
+    for seed in (0, 1, 42, 4357, 123456789, 2**32 - 1):
+        r = O.Rng(seed, L)
+        got = np.array([L.gsl_rng_get(r.r) for _ in range(20000)], dtype=np.uint64)
+        assert np.array_equal(got, _numpy_mt(seed, 20000)), seed
+
+
+def _ziggurat_restated(raw, sigma, tabs):
+    """The published 128-level ziggurat (Marsaglia & Tsang 2000 in J. Voss's layout for GSL) written out again in
+    Python over a list of raw 32-bit draws: level = low 7 bits, sign = bit 7, 24-bit mantissa j; accept when
+    j < k[level]; otherwise a wedge test against exp(-x^2/2) with one more uniform, or the exponential tail beyond R
+    with two.  Returns (variates, raw draws used)."""
+    R, ytab, ktab, wtab = tabs
+    out, pos = [], 0
+
+    def uniform():
+        nonlocal pos
+        v = raw[pos] / 4294967296.0
+        pos += 1
+        return v
+
+    n = len(raw) - 8
+    while pos < n:
+        while True:
+            k = raw[pos]
+            pos += 1
+            i, j = k & 0xFF, (k >> 8) & 0xFFFFFF
+            sign = 1.0 if (i & 0x80) else -1.0
+            i &= 0x7F
+            x = j * wtab[i]
+            if j < ktab[i]:
+                break
+            if i < 127:
+                y0, y1 = ytab[i], ytab[i + 1]
+                y = y1 + (y0 - y1) * uniform()
+            else:
+                u1 = 1.0 - uniform()
+                u2 = uniform()
+                x = R - np.log(u1) / R
+                y = np.exp(-R * (x - 0.5 * R)) * u2
+            if y < np.exp(-0.5 * x * x):
+                break
+        out.append(sign * sigma * x)
+    return out, pos
+
+
+def test_ziggurat_equals_an_independent_restatement_over_numpys_stream():
+    """The Gaussian proposals of oracle AND product come from one C file (gslcompat.c).  Here its stream is compared,
+    bit for bit, with a Python restatement of the published algorithm running on numpy's MT19937 and on tables parsed
+    from the generator script's output: 3 seeds x 10^5 variates, wedge and tail branches included.  (GSL itself is
+    absent: "parity unpinned" against libgsl, as for the tables.)"""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = subprocess.check_output([sys.executable, os.path.join(root, "tools", "gen_ziggurat_tables.py")], text=True)
+    R = float(re.search(r"ZIG_PARAM_R (\S+)", text).group(1))
+    arrays = re.findall(r"\{([^}]*)\}", text)
+    ytab = [float(v) for v in arrays[0].replace("\n", " ").split(",") if v.strip()]
+    ktab = [int(v.strip().rstrip("UL")) for v in arrays[1].replace("\n", " ").split(",") if v.strip()]
+    wtab = [float(v) for v in arrays[2].replace("\n", " ").split(",") if v.strip()]
+    assert len(ytab) == len(ktab) == len(wtab) == 128
+    L = O.lib()
+    slow = 0
+    for seed, sigma in ((0, 1.0), (7, 0.0123), (20240229, 3.5)):
+        raw = [int(v) for v in _numpy_mt(seed, 102000)]
+        want, used = _ziggurat_restated(raw, sigma, (R, ytab, ktab, wtab))
+        want = want[:100000]
+        r = O.Rng(seed, L)
+        got = [L.gsl_ran_gaussian_ziggurat(r.r, sigma) for _ in range(len(want))]
+        assert [float(v).hex() for v in got] == [float(v).hex() for v in want], seed
+        slow += used - len(want)
+    assert slow > 1000  # the non-rectangle branches were taken (about 1.2 % of the draws, each one or two uniforms)
