@@ -1,17 +1,51 @@
-"""gslcompat RNG: MT19937 against public known-answer vectors, GSL's own
-self-test value and the outputs printed in GSL's manual; ziggurat sanity."""
+"""The two restatements of GSL's random numbers -- the product's (mcmc_amd/csrc/gslcompat/gslcompat.c, inside
+libmcmc_amd.so) and the oracle's own (oracle/rng.c, inside liboracle.so): each against public known-answer
+vectors of MT19937, GSL's own self-test value and the outputs printed in GSL's manual, against numpy's MT19937 and a
+Python restatement of the ziggurat, and against each other."""
+import ctypes as C
 import json
 import os
 
 import numpy as np
+import pytest
 
 import oracle_py as O
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_product = None
 
 
-def test_mt19937_known_answers():
-    L = O.lib()
+def _product_lib():
+    """libmcmc_amd.so's gsl_* entry points (no device call is made through them)."""
+    global _product
+    if _product is None:
+        L = C.CDLL(os.path.join(ROOT, "mcmc_amd", "lib", "libmcmc_amd.so"), mode=C.RTLD_LOCAL)
+        P = C.c_void_p
+        L.gsl_rng_alloc.restype = P
+        L.gsl_rng_alloc.argtypes = [P]
+        L.gsl_rng_free.argtypes = [P]
+        L.gsl_rng_set.argtypes = [P, C.c_ulong]
+        L.gsl_rng_get.restype = C.c_ulong
+        L.gsl_rng_get.argtypes = [P]
+        L.gsl_rng_uniform.restype = C.c_double
+        L.gsl_rng_uniform.argtypes = [P]
+        L.gsl_rng_uniform_int.restype = C.c_ulong
+        L.gsl_rng_uniform_int.argtypes = [P, C.c_ulong]
+        L.gsl_ran_gaussian_ziggurat.restype = C.c_double
+        L.gsl_ran_gaussian_ziggurat.argtypes = [P, C.c_double]
+        L.gsl_ran_gaussian_pdf.restype = C.c_double
+        L.gsl_ran_gaussian_pdf.argtypes = [C.c_double, C.c_double]
+        _product = L
+    return _product
+
+
+@pytest.fixture(params=["oracle", "product"])
+def L(request):
+    return O.lib() if request.param == "oracle" else _product_lib()
+
+
+def test_mt19937_known_answers(L):
     r = O.Rng(5489, L)
     v = [L.gsl_rng_get(r.r) for _ in range(10000)]
     assert v[:5] == [3499211612, 581869302, 3890346734, 3586334585, 545404204]  # mt19937ar.c
@@ -22,8 +56,7 @@ def test_mt19937_known_answers():
     assert GOLD["mt19937"]["seed5489_10000th"] == v[-1]
 
 
-def test_seed_zero_is_4357_and_matches_gsl_manual():
-    L = O.lib()
+def test_seed_zero_is_4357_and_matches_gsl_manual(L):
     a, b = O.Rng(0, L), O.Rng(4357, L)
     assert [L.gsl_rng_get(a.r) for _ in range(8)] == [L.gsl_rng_get(b.r) for _ in range(8)]
     a.set(0)
@@ -33,8 +66,7 @@ def test_seed_zero_is_4357_and_matches_gsl_manual():
     assert got == GOLD["gsl_manual_seed0"]["uniform_5dp"]
 
 
-def test_uniform_and_uniform_int():
-    L = O.lib()
+def test_uniform_and_uniform_int(L):
     r = O.Rng(1, L)
     raw = [L.gsl_rng_get(r.r) for _ in range(100)]
     r.set(1)
@@ -54,8 +86,7 @@ def test_uniform_and_uniform_int():
     assert ks[:50] == exp
 
 
-def test_ziggurat_moments_and_draw_budget():
-    L = O.lib()
+def test_ziggurat_moments_and_draw_budget(L):
     r = O.Rng(0, L)
     n = 400000
     g = np.array([L.gsl_ran_gaussian_ziggurat(r.r, 2.0) for _ in range(n)])
@@ -73,8 +104,7 @@ def test_ziggurat_moments_and_draw_budget():
     assert after in raw[1000:1100]
 
 
-def test_golden_streams():
-    L = O.lib()
+def test_golden_streams(L):
     r = O.Rng(42, L)
     z = [float(L.gsl_ran_gaussian_ziggurat(r.r, 1.0)).hex() for _ in range(16)]
     assert z == GOLD["ziggurat_seed42_first16"]
@@ -83,8 +113,7 @@ def test_golden_streams():
     assert u == GOLD["uniform_seed42_first8"]
 
 
-def test_gaussian_pdf():
-    L = O.lib()
+def test_gaussian_pdf(L):
     for x, s in [(0.0, 1.0), (0.5, 10.0), (-3.0, 5.0), (2.0, -2.0)]:
         want = np.exp(-x * x / (2 * s * s)) / (np.sqrt(2 * np.pi) * abs(s))
         assert abs(L.gsl_ran_gaussian_pdf(x, s) - want) <= 4e-16 * want
@@ -109,8 +138,7 @@ def _numpy_mt(seed, n):
     return rs.randint(0, 2**32, size=n, dtype=np.uint64).astype(np.uint64)
 
 
-def test_mt19937_stream_equals_numpys_for_several_seeds():
-    L = O.lib()
+def test_mt19937_stream_equals_numpys_for_several_seeds(L):
     for seed in (0, 1, 42, 4357, 123456789, 2**32 - 1):
         r = O.Rng(seed, L)
         got = np.array([L.gsl_rng_get(r.r) for _ in range(20000)], dtype=np.uint64)
@@ -156,8 +184,8 @@ def _ziggurat_restated(raw, sigma, tabs):
     return out, pos
 
 
-def test_ziggurat_equals_an_independent_restatement_over_numpys_stream():
-    """The Gaussian proposals of oracle AND product come from one C file (gslcompat.c).  Here its stream is compared,
+def test_ziggurat_equals_an_independent_restatement_over_numpys_stream(L):
+    """The Gaussian stream of each C restatement (the oracle builds its tables itself at first use) is compared,
     bit for bit, with a Python restatement of the published algorithm running on numpy's MT19937 and on tables parsed
     from the generator script's output: 3 seeds x 10^5 variates, wedge and tail branches included.  (GSL itself is
     absent: "parity unpinned" against libgsl, as for the tables.)"""
@@ -173,7 +201,6 @@ def test_ziggurat_equals_an_independent_restatement_over_numpys_stream():
     ktab = [int(v.strip().rstrip("UL")) for v in arrays[1].replace("\n", " ").split(",") if v.strip()]
     wtab = [float(v) for v in arrays[2].replace("\n", " ").split(",") if v.strip()]
     assert len(ytab) == len(ktab) == len(wtab) == 128
-    L = O.lib()
     slow = 0
     for seed, sigma in ((0, 1.0), (7, 0.0123), (20240229, 3.5)):
         raw = [int(v) for v in _numpy_mt(seed, 102000)]
@@ -184,3 +211,18 @@ def test_ziggurat_equals_an_independent_restatement_over_numpys_stream():
         assert [float(v).hex() for v in got] == [float(v).hex() for v in want], seed
         slow += used - len(want)
     assert slow > 1000  # the non-rectangle branches were taken (about 1.2 % of the draws, each one or two uniforms)
+
+
+def test_oracle_and_product_streams_are_the_same_numbers():
+    """Two separately written files, one stream: raw draws, uniforms, bounded integers and Gaussians interleaved the
+    way the samplers draw them (d Gaussians, one uniform; mcmc_cpu.c:53,58)."""
+    A, B = O.lib(), _product_lib()
+    for seed in (0, 3, 987654321):
+        ra, rb = O.Rng(seed, A), O.Rng(seed, B)
+        for it in range(30000):
+            for _ in range(3):
+                assert A.gsl_ran_gaussian_ziggurat(ra.r, 0.37) == B.gsl_ran_gaussian_ziggurat(rb.r, 0.37), (seed, it)
+            assert A.gsl_rng_uniform(ra.r) == B.gsl_rng_uniform(rb.r), (seed, it)
+            if it % 100 == 0:
+                assert A.gsl_rng_uniform_int(ra.r, 16) == B.gsl_rng_uniform_int(rb.r, 16)
+                assert A.gsl_rng_get(ra.r) == B.gsl_rng_get(rb.r)
