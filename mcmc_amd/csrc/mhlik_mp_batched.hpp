@@ -202,6 +202,10 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__r
   const int64_t all = (int64_t)p.blocks << p.block_shift;
   const int64_t covered = all < p.n_rows ? all : p.n_rows; // rows that belong to a considered block
   const float epsf = (float)p.eps;
+  // product form of a lane's dark terms (see epi): c = eps / (1 - eps), 16 log(1 - eps), and the largest dot it takes:
+  // c e^x <= 2e-4 (first-order log, error 2e-8) and x <= 7 (eight factors 1 + e^x stay far below the float range)
+  const float cfac = (float)(p.eps / (1.0 - p.eps)), l1e16 = (float)(16.0 * log1p(-p.eps));
+  const float xlim = fminf(7.0f, logf(2e-4f / cfac));
   double sum[NB];
 #pragma unroll
   for (int n = 0; n < NB; n++) sum[n] = 0.0;
@@ -217,10 +221,36 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_x3_kernel(const float *__r
       const int8_t zc = z[blk * kBatchCols + n * 16 + ccol];
       float s = 0.f;
       if (lim == 64) { // wave-uniform
+        // A lane's 16 terms in product form: log(sigma - eps) = log(1 - eps) + log(1 - c e^x) - log(1 + e^x) with
+        // c = eps / (1 - eps); while c e^x <= 2e-4 its log is -c e^x to 2e-8 (below the float sum's own rounding),
+        // and the 1 + e^x multiply up eight at a time (< 1.1e3^8 for x <= 7): one v_exp_f32 per element and two
+        // v_log_f32 per 16 instead of exp + rcp + log each.  A group that holds an x > xlim (or +inf) anywhere in
+        // the wave takes the per-element form; NaN travels through the sums.
+        float sq0 = 0.f, sq1 = 0.f, pd0 = 1.f, pd1 = 1.f, xm = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-          for (int m = 0; m < 4; m++) s += mpb_dark_term(acc[m][n][r], epsf);
+          for (int m = 0; m < 4; m++) {
+            const float x = acc[m][n][r];
+            const float q = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+            __asm__("v_max_f32 %0, %1, %2" : "=v"(xm) : "v"(xm), "v"(x)); // no canonicalisation of x first
+            if (r < 2) {
+              sq0 += q;
+              pd0 = fmaf(pd0, q, pd0);
+            } else {
+              sq1 += q;
+              pd1 = fmaf(pd1, q, pd1);
+            }
+          }
+        s = fmaf(-cfac, sq0 + sq1, l1e16) -
+            0.69314718055994531f * (__builtin_amdgcn_logf(pd0) + __builtin_amdgcn_logf(pd1));
+        if (__builtin_amdgcn_ballot_w64(!(xm <= xlim)) != 0) { // wave-uniform, rare
+          s = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) s += mpb_dark_term(acc[m][n][r], epsf);
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++)

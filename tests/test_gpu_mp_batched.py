@@ -106,6 +106,51 @@ def test_mp_batched_chain_equals_single_chain_path():
                 assert abs(bv[k] - v) <= 2e-6 * abs(v)
 
 
+@pytest.mark.parametrize("eps", [1.7e-7, 1e-4])
+@pytest.mark.parametrize("scale", [0.3, 3.0, 6.0])
+def test_mp_batched_dark_terms_product_form_and_its_limits(scale, eps):
+    """The split dark pass adds a lane's 16 terms log(sigma - eps) in product form while every dot of the group is
+    below min(7, log(2e-4 (1 - eps) / eps)), and element by element otherwise: small, large (|x| up to ~12) and
+    overflowing (x > 15.6: sigma < eps, NaN in the definition as well) dots, and an eps for which the limit is 0.69,
+    each against the CPU restatement chain by chain and against the exact float mode (per-element terms)."""
+    from mcmc_amd import Likelihood
+    from mcmc_amd.likelihood import synthetic_host
+
+    N, d, block_rows, K, rf = 8192, 6, 64, 16, 2
+    blocks = N // block_rows
+    X = synthetic_host(31, N, d)
+    Xf = np.asfortranarray(X.astype(np.float32))
+    z = np.ones((K, blocks), dtype=np.int8)
+    seeds = np.arange(500, 500 + K, dtype=np.uint64)
+    rng = np.random.default_rng(8)
+    Ths = [rng.normal(0, scale, (K, d)) for _ in range(4)]
+    got = {}
+    for mode in ("split", "exact"):
+        with Likelihood(N, d, precision=3, segments=1) as lk:
+            lk.upload(X)
+            lk.upload(Xf)
+            lk.mp_reset_batched(block_rows, blocks, K)
+            lk.set_batched_f32_mode(mode)
+            got[mode] = [lk.mp_loglik_batched(Ths[c], rf, np.full(K, c % rf, dtype=np.int32), seeds, c, eps)
+                         for c in range(4)]
+    nan_seen = False
+    for c in range(4):
+        for k in range(K):
+            want, wb, wd = _oracle_mp(X, Xf, Ths[c][k], block_rows, blocks, rf, c % rf, int(seeds[k]), c, eps, z[k])
+            for mode in ("split", "exact"):
+                v, nb, nd = got[mode][c]
+                assert (nb[k], nd[k]) == (wb, wd), (mode, c, k)
+                if np.isnan(want):
+                    nan_seen = True
+                    assert np.isnan(v[k]), (mode, c, k, v[k])
+                else:
+                    assert abs(v[k] - want) <= 2e-6 * abs(want), (mode, c, k, v[k], want)
+    # the inputs really reach the regimes named above
+    xmax = max(float(np.max(X @ Ths[c].T)) for c in range(4))
+    assert (xmax < 3.0) if scale == 0.3 else (xmax > 7.0 if scale == 3.0 else xmax > 15.6), xmax
+    assert nan_seen or scale < 6.0
+
+
 @pytest.mark.parametrize("N,d,block_rows", [(400000, 4, 64), (1500000, 3, 256)])
 def test_mp_batched_dense_correction_in_rounds_equals_single_chain_path(N, d, block_rows):
     """24 blocks per workgroup of the dense correction kernel: with everything bright (the first call) a workgroup
