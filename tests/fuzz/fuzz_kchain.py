@@ -2,13 +2,13 @@
 """Random shapes of the K-chain C samplers: the device-resident lock-step loop (chunk pipeline, helper thread) against
 the per-iteration host loop (MCMC_AMD_HOST_LOOP=1) on the same generators -- samples, burn rows and accept counts bit for
 bit, in double, float (both MFMA modes) and mixed precision (shared phase / phase per chain); and chain 0 of the double
-run against the CPU restatement's cpu_sampler.  Development tool, GPU box.  python tools/fuzz_kchain.py [cases] [seed]"""
+run against the CPU restatement's cpu_sampler.  Run by hand on the GPU box, not collected by pytest.  python tests/fuzz/fuzz_kchain.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py as O  # noqa: E402

@@ -2,13 +2,13 @@
 """Random shapes of the mixed-precision K-chain evaluation (dark pass in both float modes; dense and per-(block, chain)
 correction) against the single-chain HIP path chain by chain: identical indicator counts, values within 2e-6 relative
 plus one float rounding (1e-7) per row -- a float sum of terms near zero is only that good in either path
-(development tool, GPU box).  python tools/fuzz_mp.py [cases] [seed]"""
+(checker run by hand on the GPU box, not collected by pytest).  python tests/fuzz/fuzz_mp.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mcmc_amd import Likelihood  # noqa: E402
 

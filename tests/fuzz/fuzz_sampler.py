@@ -2,13 +2,13 @@
 """Random shapes of the DP sampler on the MI355X against the CPU restatement's cpu_sampler with the same seed: the
 accept / reject sequence, every sample and burn-in row bit for bit, likelihood trace within 1e-10 (development tool, GPU
 box).  A run whose smallest decision margin |log u - ratio| is below 1e-8 is reported, not failed, if it diverges there.
-python tools/fuzz_sampler.py [cases] [seed]"""
+python tests/fuzz/fuzz_sampler.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py as O  # noqa: E402

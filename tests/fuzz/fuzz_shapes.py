@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Random shapes through the C-ABI against the CPU restatement (development tool, GPU box; uses tests/oracle_py.py as
+"""Random shapes through the C-ABI against the CPU restatement (checker run by hand on the GPU box, not collected by pytest; uses tests/oracle_py.py as
 the checker): single evaluations in double and float, K-chain passes in all float / double modes, and the
 device-resident chain in its one-launch and two-kernel forms against each other and against a host loop over single
-evaluations.  python tools/fuzz_shapes.py [cases] [seed]"""
+evaluations.  python tests/fuzz/fuzz_shapes.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py as O  # noqa: E402

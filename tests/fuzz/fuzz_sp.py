@@ -3,13 +3,13 @@
 tests/test_gpu_samplers.py::test_sp_sampler_host_arithmetic_against_teacher_forced_oracle): log u, accept bits, samples
 and burn rows equal, ratio equal (host loop) or within one float ulp (device loop), every fed likelihood within 1e-4
 of the DP value at the oracle's own proposal (plus one float rounding of 1 + e^x per row: the reference's float
-formula log(1 + exp(x)) loses the small terms the same way).  Development tool, GPU box.  python tools/fuzz_sp.py [cases] [seed]"""
+formula log(1 + exp(x)) loses the small terms the same way).  Run by hand on the GPU box, not collected by pytest.  python tests/fuzz/fuzz_sp.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py as O  # noqa: E402
