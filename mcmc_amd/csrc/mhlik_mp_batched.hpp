@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock, 2) void mpb_dark_kernel(const float *__rest
     const int64_t g0 = p.row_base + tile * kMpTileRows + row0; // global row of the pass's first row
     if (g0 >= covered) break;                                  // wave-uniform
     f32x16 acc[4][NB];
-    batched_f32_pass<NB, KU, 0>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
+    batched_f32_pass<NB, KU>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
     // indicators of the two 64-row groups of this pass (a group never straddles a data block)
     int8_t zc[2][NB];
 #pragma unroll

@@ -52,5 +52,6 @@ def test_lab_kernel_with_all_switches_off_is_the_product_kernel(tmp_path):
 
 
 def test_product_header_has_no_lab_switches():
-    text = open(os.path.join(ROOT, "mcmc_amd", "csrc", "mhlik_batched_x3.hpp")).read()
-    assert "EXP" not in text and "lab:" not in text and "Lab variant" not in text
+    for name in ("mhlik_batched_x3.hpp", "mhlik_batched.hpp", "mhlik_mp_batched.hpp", "mhlik_kernels.hpp", "mhlik_chain.hpp"):
+        text = open(os.path.join(ROOT, "mcmc_amd", "csrc", name)).read()
+        assert "EXP" not in text and "lab:" not in text and "Lab variant" not in text and "dbg" not in text, name

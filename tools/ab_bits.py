@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Bitwise A/B of two builds of libmhlik.so on one box: the K-chain passes (split float, mixed precision with a shared
-phase and with per-chain phases) on the same inputs; prints a digest per library (child process each), and whether they
+"""Bitwise A/B of two builds of libmhlik.so on one box: the K-chain passes (float in both MFMA modes, double with both epilogues,
+mixed precision with a shared phase and with per-chain phases; the exact float mode's dark pass too) on the same inputs; prints a digest per library (child process each), and whether they
 agree.  usage: python tools/ab_bits.py libA.so libB.so"""
 import hashlib
 import os
@@ -23,11 +23,17 @@ def child(lib):
         Th = rng.normal(0, 0.02, (K, d))
         with Likelihood(N, d, precision=3, segments=1) as lk:
             lk.fill_synthetic(12345)
+            for mode in ("split", "exact"):  # three bf16 pieces / f32 MFMA
+                lk.set_batched_f32_mode(mode)
+                h.update(lk.loglik_batched(Th.astype(np.float32), dtype=np.float32).tobytes())
+            for mode in ("fast", "exact"):   # f64 MFMA, product-form / per-element epilogue
+                lk.set_batched_f64_mode(mode)
+                h.update(lk.loglik_batched(Th).tobytes())
             lk.set_batched_f32_mode("split")
-            h.update(lk.loglik_batched(Th.astype(np.float32), dtype=np.float32).tobytes())
             blocks = (N + 63) // 64
             seeds = (7 + np.arange(K)).astype(np.uint64)
-            for shared in (True, False):
+            for shared, fmode in ((True, "split"), (False, "split"), (True, "exact")):
+                lk.set_batched_f32_mode(fmode)
                 lk.mp_reset_batched(64, blocks, K)
                 for call in range(3):
                     ph = np.full(K, call % 8, dtype=np.int32) if shared else rng.integers(0, 8, K).astype(np.int32)

@@ -8,6 +8,7 @@
 #include "batched_lab_v2.hpp"
 #include "batched_lab_v3.hpp"
 #include "batched_lab_f64_ilv.hpp"
+#include "batched_lab_variants.hpp"
 #include <string.h>
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -53,7 +54,7 @@ int main(int argc, char **argv)
     TileGeom g{(int64_t)tile_rows * d, tile_rows, d};
     size_t lds = sizeof(float) * d * 64 + sizeof(double) * 4 * 2 * 64;
 #define RUN32(EXPV, label) RUN32K(8, EXPV, label)
-#define RUN32K(KUV, EXPV, label) { auto k = lik_batched_f32_kernel<2, KUV, EXPV>; \
+#define RUN32K(KUV, EXPV, label) { auto k = lab_lik_batched_f32_kernel<2, KUV, EXPV>; \
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K); }, reps); \
       printf("f32 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }
@@ -66,7 +67,7 @@ int main(int argc, char **argv)
     RUN32(0, "current (again)")
     {
       std::vector<double> h1((size_t)ntiles * 64);
-      auto k1 = lik_batched_f32_kernel<2, 4, 0>;
+      auto k1 = lab_lik_batched_f32_kernel<2, 4, 0>;
       hipLaunchKernelGGL(k1, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K);
       CK(hipMemcpy(h1.data(), P, sizeof(double) * ntiles * 64, hipMemcpyDeviceToHost));
       double *P2; CK(hipMalloc(&P2, sizeof(double) * ntiles * 2 * 64));
@@ -116,7 +117,7 @@ int main(int argc, char **argv)
     TileGeom g{(int64_t)tile_rows * d, tile_rows, d};
     size_t lds = sizeof(double) * d * 64 + sizeof(double) * 4 * 4 * 64;
 #define RUN64(EXPV, label) RUN64K(2, EXPV, label)
-#define RUN64K(KUV, EXPV, label) { auto k = lik_batched_f64_kernel<4, KUV, EXPV>; \
+#define RUN64K(KUV, EXPV, label) { auto k = lab_lik_batched_f64_kernel<4, KUV, EXPV>; \
       CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds, 0, X, g, tv, th, d, P, (int64_t)ntiles, K, d * 64); }, reps); \
       printf("f64 %-28s %.3f ms  %.1f TF\n", label, ms, flops / ms / 1e9); }

@@ -1,91 +1,18 @@
-// mhlik_batched.hpp -- K proposals per pass: X.Theta on the CDNA4 matrix cores.
-//
-// No counterpart in the reference (one chain, one theta per likelihood call,
-// src/mcmc_gpu/mcmc_gpu.cu:101-107); BASELINE.json config 5.  With K = 64
-// proposals the pass does 2*K = 128 flop per matrix element instead of 2, which
-// moves it from the HBM roof to the MFMA roof (f32: 157 TF dense, f64: 78.6 TF).
-//
-// The design matrix is already in the layout an MFMA A-operand wants: inside a
-// tile it is column-major, so "one row per lane, one column per k" is a
-// coalesced read.  Each lane loads 16 bytes (4 floats / 2 doubles = VEC
-// adjacent rows of one column); element m of the load feeds the m-th of VEC
-// independent MFMA row sets.  Which physical row sits in which MFMA row does
-// not matter -- the result is summed over rows -- as long as the pad rows of a
-// ragged tile can be identified, which the C-layout formula below does.
-// Theta (d x 64, zero padded) sits in LDS in B-operand order.
-//
-//   f32: v_mfma_f32_32x32x2_f32   A[i=l&31][k=l>>5], B[k=l>>5][n=l&31],
-//        C: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
-//        (bit-for-bit a k-ordered fmaf chain: the same row dots as the
-//        single-theta float kernel)
-//   f64: v_mfma_f64_16x16x4_f64   A[i=l&15][k=l>>4], B[k=l>>4][n=l&15],
-//        C: col = l&15, row = (l>>4) + 4*r, r in [0,4)
-//
-// (f64: mhlik_neg_softplus, the same function in half the FP64 instructions of
-// exp followed by log -- the epilogue shares the FP64 lanes with the MFMA.)
-// Epilogue: -log(1+exp(.)) on every accumulator element, per-chain sum over
-// the tile's rows (registers -> LDS -> fixed order), one partial per (chain,
-// tile): partials[chain*pstride + tile], reduced by segment_sum_kernel.
+// batched_lab_variants.hpp -- LAB copies of the f32-MFMA and f64-MFMA K-chain kernels of mcmc_amd/csrc/mhlik_batched.hpp
+// with the experiment switches of rounds 1-2 (EXP bits: 1 plain sum instead of the epilogue, 2 no global loads inside the
+// k-loop, 4 ocml log1p/exp per element (f64), 8 product-form epilogue (f64)).  The product header carries none of
+// them; nothing under mcmc_amd/ includes this file.  tools/batched_lab.hip and tools/x3_lab.hip time these.
 #pragma once
 
-#include <type_traits>
-
-#include "mhlik_kernels.hpp"
-#include "mhlik_softplus.h"
+#include "mhlik_batched.hpp"
 
 namespace mhlik {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kBatchCols = 64; // chains per pass (Theta is zero padded to this)
-
-// Fast float -log(1+exp(x)) on the hardware exp2/log2 units (v_exp_f32,
-// v_log_f32, ~1 ulp each).  Overflows to -inf above ~88.7 like expf does.
-__device__ __forceinline__ float neg_log1pexp_fast(float x)
-{
-  const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-  return -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);
-}
-
-// Product form of the float epilogue (the float twin of mhlik_softplus.h's): a lane needs the SUM of
-// log(1 + e^x) over its rows, and  sum_i log(1 + e^x_i) = sum_i max(x_i, 0) + log prod_i (1 + e^-|x_i|).
-// Every factor lies in (1, 2], so up to 64 of them are multiplied without rescaling (the callers take the log
-// after at most 64) and the lane takes ONE log per group: per element one v_exp_f32 and four full-rate
-// instructions instead of v_exp_f32 + v_log_f32 and five.  prod + prod*y is a single rounding of prod*(1 + y);
-// over 64 factors the product is within ~5e-7 relative, i.e. the log within 5e-7 ABSOLUTE on a value of order
-// 40 -- less than the float additions of 64 separate terms lose.
-struct SoftplusAccF {
-  float lin = 0.f;   // sum of max(x, 0)
-  float prod = 1.f;  // product of (1 + e^-|x|)
-  __device__ __forceinline__ void add(float x)
-  {
-    float pos; // one v_max_f32 (fmaxf() canonicalises x first); NaN -> 0 here, and NaN again through the product
-    __asm__("v_max_f32 %0, %1, 0" : "=v"(pos) : "v"(x));
-    lin += pos;
-    prod = fmaf(prod, __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f), prod);
-  }
-  // -inf above the point where the reference's float formula overflows (expf(x) = inf for x > 88.72): the adds do
-  // not test for it; a group whose linear part got that far is looked over again, element by element
-  static constexpr float kOverflow = 88.7228394f;
-  __device__ __forceinline__ void flag_overflow(float x)
-  {
-    if (x > kOverflow) lin = __builtin_inff();
-  }
-  __device__ __forceinline__ float neg_sum() const { return -(lin + 0.69314718055994531f * __builtin_amdgcn_logf(prod)); }
-  __device__ __forceinline__ void reset()
-  {
-    lin = 0.f;
-    prod = 1.f;
-  }
-};
 
 // One 128-row pass of a wave: acc[m][n] = rows {row0 + 4i + m} x chains of
 // N-block n, accumulated over all d columns.  ubase = tile + row0 (wave-uniform): a load's address is a
 // scalar base (column of the k-step) plus one 32-bit per-lane byte offset, not a 64-bit VGPR pair per load.
-template <int NB, int KU>
-__device__ __forceinline__ void batched_f32_pass(const float *__restrict__ ubase, int64_t col_stride, int d,
+template <int NB, int KU, int EXP>
+__device__ __forceinline__ void lab_batched_f32_pass(const float *__restrict__ ubase, int64_t col_stride, int d,
                                                  const float *thetaL, int arow, int kk, f32x16 (&acc)[4][NB])
 {
   typedef Vec16<float>::type V4;
@@ -125,11 +52,11 @@ __device__ __forceinline__ void batched_f32_pass(const float *__restrict__ ubase
   if (nfull > 0) load_batch(bufA, 0);
   int bt = 0;
   for (; bt + 1 < nfull; bt += 2, j0 += 4 * KU) {
-    load_batch(bufB, j0 + 2 * KU);
+    if (!(EXP & 2)) load_batch(bufB, j0 + 2 * KU);
     __builtin_amdgcn_sched_barrier(0); // keep the loads ahead of the MFMAs: the scheduler sinks them otherwise
     mfma_batch(bufA, j0);
     __builtin_amdgcn_sched_barrier(0);
-    if (bt + 2 < nfull) load_batch(bufA, j0 + 4 * KU);
+    if (!(EXP & 2) && bt + 2 < nfull) load_batch(bufA, j0 + 4 * KU);
     __builtin_amdgcn_sched_barrier(0);
     mfma_batch(bufB, j0 + 2 * KU);
     __builtin_amdgcn_sched_barrier(0);
@@ -156,10 +83,12 @@ __device__ __forceinline__ void batched_f32_pass(const float *__restrict__ ubase
 // Workgroup = 256 threads = 4 waves; f32 tile = 1024 rows; wave w owns rows
 // [256w, 256w+256) in two passes of 128 rows (32 A-rows x 4 row sets).
 // NB = number of 32-chain blocks (1: K <= 32, 2: K <= 64).  KU = k-steps
-// (pairs of columns) whose loads are in flight together.
+// (pairs of columns) whose loads are in flight together.  EXP != 0 builds the
+// ablations tools/batched_lab.hip times (bit 0: plain sum instead of the
+// transcendental epilogue, bit 1: no global loads inside the k-loop).
 // LDS: thetaL[(j*32 + c)*2 + n] = Theta[j][n*32 + c]  (float2 per (j, c)).
-template <int NB, int KU>
-__global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float *__restrict__ X, TileGeom g,
+template <int NB, int KU, int EXP = 0>
+__global__ __launch_bounds__(kBlock, 2) void lab_lik_batched_f32_kernel(const float *__restrict__ X, TileGeom g,
                                                                     const int32_t *__restrict__ tile_valid,
                                                                     const float *__restrict__ theta_dev, int d_pad,
                                                                     double *__restrict__ partials, int64_t pstride,
@@ -191,7 +120,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
   for (int pass = 0; pass < 2; pass++) {
     const int row0 = wave * 256 + pass * 128; // first tile row of this pass
     f32x16 acc[4][NB];
-    batched_f32_pass<NB, KU>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
+    lab_batched_f32_pass<NB, KU, EXP>(tbase + row0, g.col_stride, d, thetaL, arow, kk, acc);
 
     // epilogue: accumulator (m, n, r) of lane l is tile row  row0 + 4*i + m  with
     // i = (r&3) + 8*(r>>2) + 4*(l>>5), chain n*32 + (l&31)
@@ -210,17 +139,24 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
             if (ok) fn(n, acc[m][n][r]);
         }
     };
-    auto add = [&](int n, float x) { sp[n].add(x); };
+    auto add = [&](int n, float x) {
+      if (EXP & 1)
+        sp[n].lin -= x;
+      else
+        sp[n].add(x);
+    };
     if (row0 + 128 <= valid)
       each(std::true_type{}, add);
     else
       each(std::false_type{}, add);
-    bool look = false;
+    if (!(EXP & 1)) {
+      bool look = false;
 #pragma unroll
-    for (int n = 0; n < NB; n++) look |= sp[n].lin > SoftplusAccF::kOverflow;
-    if (look) each(std::false_type{}, [&](int n, float x) { sp[n].flag_overflow(x); });
+      for (int n = 0; n < NB; n++) look |= sp[n].lin > SoftplusAccF::kOverflow;
+      if (look) each(std::false_type{}, [&](int n, float x) { sp[n].flag_overflow(x); });
+    }
 #pragma unroll
-    for (int n = 0; n < NB; n++) sum[n] += sp[n].neg_sum();
+    for (int n = 0; n < NB; n++) sum[n] += (EXP & 1) ? -sp[n].lin : sp[n].neg_sum();
   }
 
   // per-chain sum over the workgroup: [wave][n][lane] -> thread per chain, fixed order
@@ -243,9 +179,9 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f32_kernel(const float 
 // NB = number of 16-chain blocks (1..4).  One k-step = 4 columns.
 // LDS: thetaL[(j*16 + c)*4 + n] = Theta[j][n*16 + c]  (4 doubles per (j, c)); the per-chain reduction buffer
 // [4 waves][NB][64 lanes] reuses that region once the last MFMA has read Theta (theta_doubles >= 4*NB*64).
-// FAST: the product-form epilogue of mhlik_softplus.h (one log per lane and chain block instead of one per element).
-template <int NB, int KU, bool FAST>
-__global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double *__restrict__ X, TileGeom g,
+// EXP & 8: the product-form epilogue of mhlik_softplus.h (one log per lane and chain block instead of one per element).
+template <int NB, int KU, int EXP = 0>
+__global__ __launch_bounds__(kBlock, 2) void lab_lik_batched_f64_kernel(const double *__restrict__ X, TileGeom g,
                                                                     const int32_t *__restrict__ tile_valid,
                                                                     const double *__restrict__ theta_dev, int d_pad,
                                                                     double *__restrict__ partials, int64_t pstride,
@@ -270,7 +206,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
   const int kk = lane >> 4;   // which of the four columns of a k-step
   const double *tbase = X + tile * g.tile_stride;
   double sum[NB];
-  mhlik_softplus_acc pacc[NB]; // FAST: 32 elements per lane and chain block over the two passes
+  mhlik_softplus_acc pacc[NB]; // EXP & 8: 32 elements per lane and chain block over the two passes
 #pragma unroll
   for (int n = 0; n < NB; n++) {
     sum[n] = 0.0;
@@ -281,7 +217,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
   V2 n0[KU], n1[KU]; // the k-batch in flight
   // the first k-batch of a pass: requested before the previous pass's epilogue, so that it lands under it
   auto first_batch = [&](int pass) {
-    if (nfull > 0) {
+    if (nfull > 0 && !(EXP & 2)) {
       const double *rb = tbase + wave * 128 + pass * 64 + 2 * arow;
 #pragma unroll
       for (int u = 0; u < KU; u++) {
@@ -291,6 +227,10 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
       }
     }
   };
+  if (EXP & 2) {
+#pragma unroll
+    for (int u = 0; u < KU; u++) n0[u] = n1[u] = V2{1.0 + lane, 2.0 + u};
+  }
   first_batch(0);
 
 #pragma unroll 1
@@ -313,7 +253,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
         a0[u] = n0[u];
         a1[u] = n1[u];
       }
-      if (bt + 1 < nfull) {
+      if (!(EXP & 2) && bt + 1 < nfull) {
 #pragma unroll
         for (int u = 0; u < KU; u++) {
           const double *col = rbase + (int64_t)(j0 + 4 * KU + 4 * u + kk) * g.col_stride;
@@ -376,10 +316,10 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
 #pragma unroll
           for (int n = 0; n < NB; n++)
             if (ok) {
-              if constexpr (FAST)
+              if constexpr ((EXP & 8) != 0)
                 mhlik_softplus_acc_add(&pacc[n], acc[m][n][r]);
               else
-                sum[n] += mhlik_neg_softplus(acc[m][n][r]);
+                sum[n] += (EXP & 1) ? acc[m][n][r] : (EXP & 4) ? neg_log1pexp(acc[m][n][r]) : mhlik_neg_softplus(acc[m][n][r]);
             }
         }
     };
@@ -387,7 +327,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
       epilogue(std::true_type{});
     else
       epilogue(std::false_type{});
-    if constexpr (FAST) {
+    if constexpr ((EXP & 8) != 0) {
       // the fast adds leave out the tests for the reference's overflow to -inf above 709.78 and for arguments
       // beyond the range reduction's reach: a group that looks suspect is redone from its state before the pass
       // while its elements are still in the accumulators
@@ -405,7 +345,7 @@ __global__ __launch_bounds__(kBlock, 2) void lik_batched_f64_kernel(const double
     }
   }
   __syncthreads(); // every wave is done with Theta: the reduction buffer takes its place
-  if constexpr (FAST) {
+  if constexpr ((EXP & 8) != 0) {
     // product form: a chain's 16 lane groups are merged first, one log per (tile, chain)
     double *red_prod = red + 4 * NB * 64;
 #pragma unroll

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <vector>
 #include "x3_lab_variants.hpp"
+#include "batched_lab_variants.hpp"
 using namespace mhlik;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -91,7 +92,7 @@ int main(int argc, char **argv)
   };
   size_t lds32 = sizeof(float) * d * 64 + sizeof(double) * 4 * 2 * 64;
   size_t lds3 = img3.size() * 4 + sizeof(double) * 4 * 4 * 64;
-#define RUN32(EXPV, label) { auto k = lik_batched_f32_kernel<2, 8, EXPV>; \
+#define RUN32(EXPV, label) { auto k = lab_lik_batched_f32_kernel<2, 8, EXPV>; \
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
     float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(ntiles), dim3(256), lds32, 0, X, g, tv, th32, d, P, (int64_t)ntiles, K); }, reps); \
     CK(hipDeviceSynchronize()); report(label, ms, (EXPV) & 1); }
