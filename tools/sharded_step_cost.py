@@ -32,10 +32,12 @@ def main():
         with Likelihood(rows, d, precision=F64, device=0, rank=0, world=1, timing=True) as lk:
             lk.fill_synthetic(12345)
             if with_comm:
+                os.environ["MHLIK_FORCE_COMM"] = "1"  # a one-rank communicator is skipped otherwise
                 lk.comm_init(Likelihood.make_comm_id())
+                assert lk.comm_ranks() == 1, lk.comm_ranks()
             el, kms, acc = bench.run_c_sampler(a, lk, S, np, rows, d, steps, 300, rwsd, barrier)
-            print("rows %d  %-28s %8.1f it/s  %.2f us per iteration, kernel %.2f us, beside the kernel %.2f us  (%s)" %
-                  (rows, "one-rank RCCL communicator" if with_comm else "no communicator", steps / el, el / steps * 1e6,
+            print("rows %d  comm_ranks %d  %-28s %8.1f it/s  %.2f us per iteration, kernel %.2f us, beside the kernel %.2f us  (%s)" %
+                  (rows, lk.comm_ranks(), "one-rank RCCL communicator" if with_comm else "no communicator", steps / el, el / steps * 1e6,
                    kms * 1e3, el / steps * 1e6 - kms * 1e3, lk.last_kernel_name()), flush=True)
 
 
