@@ -36,8 +36,9 @@ def main():
         tag = "case %d n=%d d=%d lags=%d rho=%.2f" % (c, n, d, lags, rho)
         both_nan = np.isnan(want) & np.isnan(got)
         scale = np.maximum(np.abs(want), 1e-300)
-        err = np.where(both_nan, 0.0, np.abs(got - want) / scale)
-        assert np.all(err <= 1e-8) or np.all(np.abs(got - want)[~both_nan] <= 1e-12), (tag, float(np.nanmax(err)))
+        with np.errstate(invalid="ignore", over="ignore"):
+            err = np.where(both_nan | (got == want), 0.0, np.abs(got - want) / scale)  # equal infinities count as equal
+        assert np.all(err <= 1e-8) or np.all(np.abs(got - want)[~both_nan] <= 1e-12), (tag, float(np.nanmax(err)), int(np.isnan(err).sum()), got[np.isnan(err)][:3], want[np.isnan(err)][:3])
         if np.isfinite(wsum):
             assert abs(gsum - wsum) <= 1e-8 * max(1.0, abs(wsum)), (tag, gsum, wsum)
         print(tag, flush=True)
